@@ -1,0 +1,295 @@
+"""CPU tests of the oracle itself (-m "not gpu"): the reference's own known-answer vectors
+(SURVEY §8 c4), the numpy-f64 goldens, and size-independent properties."""
+import numpy as np
+import pytest
+
+from conftest import rms
+from oracle import cbind as oc
+from oracle import oracle_np as onp
+
+EPS = 1.0e-4  # src/test_utils.rs:4
+
+
+def assert_almost_eq_by_element(left, right, eps=EPS):  # src/test_utils.rs:7-26
+    left, right = np.asarray(left), np.asarray(right)
+    assert left.shape == right.shape, f"lengths differ: {left.shape} vs {right.shape}"
+    assert np.all(np.abs(left.astype(np.float64) - right.astype(np.float64)) < eps)
+
+
+# ------------------------------------------------------------------ reference known answers
+def test_hanning_result(known_answers):  # src/windows.rs:28-43
+    exp = known_answers["hanning_32"]["expected"]
+    assert_almost_eq_by_element(oc.hanning(32), np.array(exp, np.float32))
+    assert_almost_eq_by_element(onp.hanning(32), np.array(exp, np.float32))
+    # the C restatement follows the f32 operation order exactly: tighter than the reference eps
+    assert np.max(np.abs(oc.hanning(32) - np.array(exp, np.float32))) < 3e-7
+
+
+def test_rectangular_result(known_answers):  # src/windows.rs:45-49
+    assert_almost_eq_by_element(oc.rectangular(4), known_answers["rectangular_4"]["expected"])
+
+
+def test_inv_hanning(known_answers):  # src/windows.rs:51-57
+    ka = known_answers["inverse"]
+    assert_almost_eq_by_element(oc.inverse(ka["input"]), np.array(ka["expected"], np.float32))
+
+
+def test_resample_noop(known_answers):  # src/resampler.rs:42-46
+    ka = known_answers["resample_noop"]
+    assert_almost_eq_by_element(oc.resample(ka["input"], ka["factor"]), ka["expected"])
+
+
+def test_resample_faster(known_answers):  # src/resampler.rs:48-54
+    ka = known_answers["resample_faster"]
+    assert_almost_eq_by_element(oc.resample(ka["input"], ka["factor"]), ka["expected"])
+
+
+def test_resample_invalid_factor_panics():  # src/resampler.rs:11
+    for f in (0, -1):
+        with pytest.raises(ValueError):
+            oc.resample([1.0, 2.0], f)
+
+
+def test_resample_slower_matches_lerp():  # src/resampler.rs:20-35
+    v = np.array([1.0, 2.0, 4.0], np.float32)
+    out = oc.resample(v, -2)
+    assert_almost_eq_by_element(out, [1.0, 1.5, 2.0, 3.0])
+    assert out.size == (v.size - 1) * 2
+    assert_almost_eq_by_element(out, onp.resample(v, -2))
+
+
+def test_lerp(known_answers):  # src/math.rs:67-80
+    for a, b, r, exp in known_answers["lerp"]["cases"]:
+        got = oc.lerp(a, b, r)
+        # the reference compares with abs eps 1e-4 in f32; at 1.4e5 the f32 ulp is 1.6e-2, so
+        # the reference's own middle case only passes because both sides round identically.
+        assert abs(got - np.float32(exp)) < max(EPS, 2 * np.spacing(np.float32(abs(exp))))
+
+
+def _basic_stretcher(window_len):  # src/stretcher.rs:163-179
+    return oc.Stretcher(sample_rate=44100, channels=2, factor=1.0, amplitude=1.0, pitch_multiple=1,
+                        window=np.ones(window_len, np.float32), buffer_secs=1.0)
+
+
+def test_ensure_input_closed_fills_with_zeros(known_answers):  # src/stretcher.rs:144-151
+    ka = known_answers["ensure_input_closed_fills_zeros"]
+    s = _basic_stretcher(ka["window_len"])
+    s.close_input()
+    s.ensure_input_samples_available(ka["n"])
+    assert s.is_done() == ka["expected_done"]
+    assert_almost_eq_by_element(s.input_buf(), ka["expected_buf"])
+
+
+def test_ensure_input_loading_multiple_chunks(known_answers):  # src/stretcher.rs:153-161
+    ka = known_answers["ensure_input_multiple_chunks"]
+    s = _basic_stretcher(ka["window_len"])
+    s.send(ka["chunks"][0])
+    # the reference recv()s chunk-wise: after the first chunk 3 < 4 so it takes the second too
+    assert s.ensure_input_samples_available(ka["n"]) == oc.RCO_WOULD_BLOCK
+    s.send(ka["chunks"][1])
+    assert s.ensure_input_samples_available(ka["n"]) == oc.RCO_OK
+    assert s.is_done() == ka["expected_done"]
+    assert_almost_eq_by_element(s.input_buf(), ka["expected_buf"])
+
+
+def test_channel_bound():  # src/stretcher.rs:82-85: ceil((N/sr)/buffer_dur)
+    s = oc.Stretcher(window=oc.hanning(16384), buffer_secs=1.0)
+    assert s.channel_bound() == 1
+    s = oc.Stretcher(window=oc.hanning(16384), buffer_secs=0.1)
+    assert s.channel_bound() == 4
+    s = oc.Stretcher(window=oc.hanning(65536), sample_rate=44100, buffer_secs=1.0)
+    assert s.channel_bound() == 2
+
+
+# ------------------------------------------------------------------ parameter derivation
+@pytest.mark.parametrize("N,f,p,step,amp,S", [
+    (16384, 1.0, 1, 8192, 4.0, 16384),
+    (16384, 8.0, 1, 1024, 4.0, 16384),    # C2
+    (16384, 8.0, 3, 341, 6.0, 49152),     # C3 (341.33 truncated)
+    (65536, 32.0, 1, 1024, 8.0, 65536),   # C5
+    (16384, 8.0, -2, 2048, 4.0, 8192),
+])
+def test_derived_constants(N, f, p, step, amp, S):  # src/stretcher.rs:42-56
+    s = oc.Stretcher(factor=f, pitch_multiple=p, window=np.ones(N, np.float32))
+    assert (s.step, s.amp, s.samples_needed_per_window) == (step, amp, S)
+    d = onp.derive(N, f, 1.0, p)
+    assert (d["step"], float(d["amp"]), d["S"]) == (step, amp, S)
+
+
+def test_invalid_parameters_rejected():
+    w = np.ones(256, np.float32)
+    with pytest.raises(ValueError):  # stretcher.rs:40 assert
+        oc.Stretcher(pitch_multiple=0, window=w)
+    with pytest.raises(ValueError):  # step == 0: the reference loops forever (stretcher.rs:55,105)
+        oc.Stretcher(factor=200.0, pitch_multiple=1, window=w)
+    with pytest.raises(ValueError):  # step > N: `len - step` underflow (stretcher.rs:105-106)
+        oc.Stretcher(factor=0.25, pitch_multiple=1, window=w)
+
+
+# ------------------------------------------------------------------ phase source spec
+def test_phase_source_known_answers(goldens):
+    z, meta = goldens
+    key = meta["hop1024"]["key"]
+    assert oc.phase_key(meta["hop1024"]["seed"], 1, 7) == key == onp.phase_key(0x5EED, 1, 7)
+    bins = z["phase/bins"]
+    assert np.array_equal(oc.phase_hash(key, bins), z["phase/hash"])
+    assert np.array_equal(onp.phase_hash(key, bins), z["phase/hash"])
+    assert np.array_equal(oc.phase_theta(key, bins), z["phase/theta"])
+
+
+def test_phase_source_range_and_statistics():
+    key = oc.phase_key(123, 0, 0)
+    th = onp.phase_theta(key, np.arange(1 << 16))
+    assert th.min() >= 0.0 and th.max() < np.float32(np.pi)  # fft.rs:13: TWO_PI == PI
+    assert abs(th.mean() - np.pi / 2) < 0.02
+    # channels / hops are independent streams (fft.rs:64 draws sequentially across channels)
+    th2 = onp.phase_theta(oc.phase_key(123, 1, 0), np.arange(1 << 16))
+    th3 = onp.phase_theta(oc.phase_key(123, 0, 1), np.arange(1 << 16))
+    for other in (th2, th3):
+        c = np.corrcoef(th, other)[0, 1]
+        assert abs(c) < 0.02
+
+
+# ------------------------------------------------------------------ one hop (fft.rs)
+def test_one_hop_golden(goldens):
+    z, meta = goldens
+    m = meta["hop1024"]
+    r = oc.ReFFT(oc.hanning(m["N"]))
+    X = r.forward_fft(z["hop1024/x"])
+    Xg = z["hop1024/spectrum"]
+    assert rms(np.abs(X - Xg)) <= 2e-6 * rms(np.abs(Xg)) + 1e-6
+    y = r.resynth(z["hop1024/x"], m["key"])
+    assert rms(y - z["hop1024/y"]) <= 1e-6
+    y2 = r.resynth_from_fft_result(Xg, m["key"])
+    assert rms(y2 - z["hop1024/y"]) <= 1e-6
+
+
+def test_forward_fft_matches_numpy_nonpow2():
+    x = onp.synth_input(0, 250)
+    w = oc.hanning(250)
+    X = oc.ReFFT(w).forward_fft(x)
+    Xn = np.fft.fft(x.astype(np.float64) * w)
+    assert rms(np.abs(X - Xn)) < 1e-5
+
+
+# ------------------------------------------------------------------ end to end goldens
+def _kernel_for(gain):
+    if gain is None:
+        return None
+    return lambda t, spec: spec * np.float32(gain)
+
+
+def test_stretch_goldens(goldens):
+    z, meta = goldens
+    for name, m in meta.items():
+        if "factor" not in m:
+            continue
+        x, y = z[name + "/x"], z[name + "/y"]
+        got = oc.stretch_offline(x, m["N"], m["factor"], m["amplitude"], m["pitch"],
+                                 seed=m["seed"], kernel=_kernel_for(m["kernel_gain"]))
+        assert got.shape == y.shape, name
+        for c in range(y.shape[0]):
+            assert rms(got[c] - y[c]) <= 2e-6 * max(1.0, rms(y[c])), name
+
+
+def test_closed_form_equals_literal_loop():
+    # O[kH+i] = (y_k[i] + y_{k-1}[H+i]) env[i] amp ; F[t] = O[t p]
+    x = onp.synth_input(0, 3000)
+    for f, p in [(1.0, 1), (8.0, 1), (0.5, 1), (2.0, 2), (8.0, 3)]:
+        a = onp.stretch_channel_literal(x, 256, f, 1.0, p, 9, 0)
+        b = onp.stretch_channel_closed(x, 256, f, 1.0, p, 9, 0)
+        assert a.size == b.size and np.max(np.abs(a - b)) == 0.0
+
+
+# ------------------------------------------------------------------ properties
+@pytest.mark.parametrize("N,L,f,p", [(256, 3000, 8.0, 1), (256, 3001, 8.0, 3), (512, 100, 2.0, 1),
+                                     (256, 256, 1.0, 1), (256, 255, 1.0, 2), (256, 0, 1.0, 1)])
+def test_output_length(N, L, f, p):
+    # len(F) = K*H/p = windows*N  (stretcher.rs:91,123-134; stretcher_processor.rs:64-69)
+    x = onp.synth_input(0, L)
+    y = oc.stretch_offline(x[None], N, f, 1.0, p, seed=1)[0]
+    step = onp.derive(N, f, 1.0, p)["step"]
+    K = onp.hop_count(L, N, step, p)
+    assert y.size == K * (N // 2) // p == oc.offline_output_len(L, N, f, p)
+    assert y.size % N == 0
+
+
+def test_zero_input_gives_zero_output():
+    y = oc.stretch_offline(np.zeros((2, 2000), np.float32), 256, 4.0, 1.0, 1, seed=5)
+    assert np.all(y == 0.0)
+
+
+def test_real_gain_kernel_is_linear():
+    # .norm() is linear: a kernel scaling by real g gives exactly g*F (same phases)
+    x = onp.synth_input(1, 2500)[None]
+    a = oc.stretch_offline(x, 256, 8.0, 1.0, 1, seed=3)
+    b = oc.stretch_offline(x, 256, 8.0, 1.0, 1, seed=3, kernel=lambda t, s: s * np.float32(2.0))
+    assert rms(b - 2.0 * a) < 1e-6
+
+
+def test_panicking_kernel_falls_back_to_noop():  # fft.rs:100-106
+    x = onp.synth_input(1, 1500)[None]
+
+    def bad(t, s):
+        raise RuntimeError("kernel panicked")
+
+    a = oc.stretch_offline(x, 256, 2.0, 1.0, 1, seed=3)
+    b = oc.stretch_offline(x, 256, 2.0, 1.0, 1, seed=3, kernel=bad)
+    assert np.array_equal(a, b)
+
+
+def test_first_half_window_contains_only_first_hop_head():
+    x = onp.synth_input(0, 3000)
+    N, H = 256, 128
+    y = oc.stretch_offline(x[None], N, 1.0, 1.0, 1, seed=11)[0]
+    r = oc.ReFFT(oc.hanning(N))
+    y0 = r.resynth(x[:N], oc.phase_key(11, 0, 0))
+    env = oc.hanning_crossfade_compensation(H)
+    assert rms(y[:H] - y0[:H] * env * np.float32(4.0)) < 1e-7
+
+
+def test_pitch_decimation_identity():
+    # F[t] = O[t*p]: the p=3 run equals every 3rd sample of the undecimated overlap-add with
+    # the same hop geometry (same step => run p=1 at factor f*p).
+    x = onp.synth_input(0, 3000)
+    N = 256
+    d3 = onp.derive(N, 2.0, 1.0, 3)
+    d1 = onp.derive(N, 6.0, 1.0, 1)
+    assert d3["step"] == d1["step"]
+    a = onp.stretch_channel_closed(x, N, 2.0, 1.0, 3, 7, 0)
+    b = onp.stretch_channel_closed(x, N, 6.0, 1.0, 1, 7, 0)
+    scale = float(d3["amp"]) / float(d1["amp"])
+    m = min(a.size, b[::3].size)
+    assert np.allclose(a[:m], b[::3][:m] * scale, atol=1e-9)
+
+
+def test_streaming_chunks_equal_single_chunk():
+    # feeding the channel in small chunks gives the same windows as one big chunk
+    x = onp.synth_input(0, 4000)
+    w = oc.hanning(256)
+    a = oc.Stretcher(factor=4.0, window=w, seed=2)
+    a.send(x)
+    a.close_input()
+    b = oc.Stretcher(factor=4.0, window=w, seed=2)
+    pos = 0
+    outs_a, outs_b = [], []
+    while not a.is_done():
+        outs_a.append(a.next_window())
+    while not b.is_done():
+        try:
+            outs_b.append(b.next_window())
+        except BlockingIOError:
+            if pos < x.size:
+                b.send(x[pos:pos + 333])
+                pos += 333
+            else:
+                b.close_input()
+    assert np.array_equal(np.concatenate(outs_a), np.concatenate(outs_b))
+
+
+def test_stereo_channels_use_independent_phases():
+    x = onp.synth_input(0, 3000)
+    y = oc.stretch_offline(np.stack([x, x]), 256, 4.0, 1.0, 1, seed=1)
+    assert not np.allclose(y[0], y[1])
+    # per-window RMS gain is stationary-ish and non-zero
+    assert 0.01 < rms(y[0]) < 1.0 and 0.01 < rms(y[1]) < 1.0
