@@ -1,0 +1,155 @@
+/*
+ * rocoder_hip.h — C-ABI of the MI355X (gfx950) stretch engine: the drop-in boundary for
+ * rocoder's analysis -> kernel -> resynthesis -> overlap-add hot path.
+ *
+ * Plain C: opaque handle, plain pointers and sizes, int status codes, no C++/torch types.
+ * Every entry point names the reference interface (file:line under the rocoder source
+ * tree, v0.4.0) that it replaces. A Rust host binds this with one `extern "C"` block
+ * (INTEGRATION.md shows the exact stub and where `Stretcher` calls into it).
+ *
+ * Threading: one thread at a time per handle (the reference calls every Stretcher from
+ * the single StretcherProcessor thread: src/stretcher_processor.rs:55-71). HIP streams,
+ * events and scratch buffers are private to the handle.
+ *
+ * The library has NO CPU fallback: every compute entry point fails with RC_ENODEVICE when
+ * no gfx950 device is usable.
+ */
+#ifndef ROCODER_HIP_H
+#define ROCODER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_ABI_VERSION 1
+
+/* status codes */
+#define RC_OK 0
+#define RC_WOULD_BLOCK 1   /* the reference would block in Receiver::recv (src/stretcher.rs:125) */
+#define RC_EINVAL (-1)     /* the reference would assert/panic/never terminate */
+#define RC_ENODEVICE (-2)  /* no usable HIP device */
+#define RC_EUNSUPPORTED (-3) /* valid for the reference, not (yet) on the GPU path */
+#define RC_ENOMEM (-4)
+#define RC_EHIP (-5)       /* HIP runtime error; see rc_last_error() */
+#define RC_ECAPACITY (-6)  /* caller buffer too small */
+
+/*
+ * User frequency kernel. C-ABI shape of the reference's hot-swapped
+ *   #[no_mangle] pub fn apply(elapsed_ms: usize, input: Vec<(f32,f32)>) -> Vec<(f32,f32)>
+ * (README.md:106-112; resolved and called at src/fft.rs:93-95). `in_reim`/`out_reim` hold
+ * n_bins == window_len interleaved (re,im) pairs in natural DFT order (ALL N bins).
+ * `time_ms` is Unix-epoch milliseconds as in src/fft.rs:89-92. A non-zero return is the
+ * equivalent of a panic (src/fft.rs:100-106): the hop falls back to the unmodified spectrum.
+ * Called on the engine's calling thread, per channel in hop order.
+ */
+typedef int (*rc_freq_kernel)(uint64_t time_ms, const float *in_reim, float *out_reim,
+                              size_t n_bins, void *user);
+
+/* Stretcher::new arguments (src/stretcher.rs:30-39) + main.rs:131-147 call-site values. */
+typedef struct rc_config {
+    uint32_t struct_size;    /* = sizeof(rc_config), ABI guard */
+    uint32_t window_len;     /* -w/--window (src/main.rs:34); power of two, 32..16384 */
+    float factor;            /* -f/--factor (src/main.rs:46-52) */
+    float amplitude;         /* -a/--amplitude */
+    int32_t pitch_multiple;  /* -p/--pitch_multiple, i8 in the reference, != 0 */
+    uint32_t sample_rate;    /* AudioSpec.sample_rate (src/audio.rs:31-37) */
+    uint32_t channels;       /* AudioSpec.channels: one Stretcher per channel (main.rs:133) */
+    float buffer_secs;       /* -b/--buffer (Duration, default 1 s) */
+    uint64_t seed;           /* phase-source seed (replaces thread_rng, src/fft.rs:64) */
+    int32_t device;          /* HIP device ordinal */
+    uint32_t max_batch_hops; /* streaming look-ahead cap per launch; 0 = default */
+    const float *window;     /* host, window_len floats; NULL = windows::hanning (main.rs:131) */
+    rc_freq_kernel kernel;   /* --freq-kernel; NULL = none */
+    void *kernel_user;
+    uint64_t kernel_time_ms; /* 0 = wall clock (src/fft.rs:89-92); non-zero = fixed (tests) */
+} rc_config;
+
+/* Values derived in Stretcher::new (src/stretcher.rs:40-56). */
+typedef struct rc_params {
+    uint32_t window_len, half_window_len;
+    uint64_t samples_needed_per_window;
+    uint32_t sample_step_len;
+    uint32_t hops_per_window; /* iterations of the loop at src/stretcher.rs:91 */
+    uint32_t window_out_len;  /* samples returned per next_window() */
+    float corrected_amp_factor;
+    float pitch_shifted_factor;
+} rc_params;
+
+typedef struct rc_engine rc_engine;
+
+/* Thread-local description of the last failure on this thread. */
+const char *rc_last_error(void);
+int rc_abi_version(void);
+/* Number of usable gfx950 devices (0 when none; never fails). */
+int rc_device_count(void);
+
+/* Pure host helpers (no device): parameter derivation of Stretcher::new
+ * (src/stretcher.rs:40-56) and the output length of an offline `-o` run
+ * (src/stretcher.rs:91,123-134 + src/stretcher_processor.rs:64-69). */
+int rc_derive_params(const rc_config *cfg, rc_params *out);
+size_t rc_offline_output_len(const rc_config *cfg, size_t in_len);
+/* Phase-source spec (replaces rand::thread_rng at src/fft.rs:64-67), exposed for tests. */
+uint64_t rc_phase_key(uint64_t seed, uint32_t channel, uint64_t hop);
+uint32_t rc_phase_hash(uint64_t key, uint32_t bin);
+
+/* Stretcher::new for all channels (src/main.rs:133-153, src/stretcher.rs:30-76) +
+ * ReFFT::new (src/fft.rs:25-40): builds window/envelope/twiddle tables on the device. */
+int rc_engine_create(const rc_config *cfg, rc_engine **out);
+void rc_engine_destroy(rc_engine *e);
+int rc_engine_get_params(const rc_engine *e, rc_params *out);
+
+/* ---- streaming seam: one call per reference call ------------------------------------- */
+/* Sender<Vec<f32>>::send on the channel's input (src/main.rs:148; src/stretcher.rs:125-127) */
+int rc_engine_push_input(rc_engine *e, uint32_t channel, const float *samples, size_t n);
+/* dropping the Sender: recv() then fails and the tail is zero-padded (src/stretcher.rs:129-132) */
+int rc_engine_close_input(rc_engine *e, uint32_t channel);
+/* Stretcher::next_window (src/stretcher.rs:87-121). Writes rc_params.window_out_len samples.
+ * RC_WOULD_BLOCK when the reference would block waiting for input. */
+int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out_cap,
+                          size_t *n_out);
+/* Stretcher::is_done (src/stretcher.rs:78-80): 1 / 0, or <0 on error. */
+int rc_engine_is_done(const rc_engine *e, uint32_t channel);
+/* Stretcher::channel_bound (src/stretcher.rs:82-85) */
+size_t rc_engine_channel_bound(const rc_engine *e);
+
+/* ---- offline fast path (`-o`, all hops known up-front) ------------------------------- */
+/* Whole-job stretch of `channels` host arrays of `in_len` samples: what main.rs:133-155 +
+ * StretcherProcessor::start (src/stretcher_processor.rs:56-71) + AudioBus::into_audio
+ * (src/audio.rs:152-172) produce. out[c] must hold rc_offline_output_len() samples. */
+int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, float *const *out,
+                           size_t out_cap, size_t *out_len);
+/* Same job on DEVICE-resident buffers (channel c at base + c*stride, strides in floats).
+ * `hip_stream` is a hipStream_t (NULL = the engine's own stream); the call is asynchronous
+ * on that stream unless a user kernel is configured. */
+int rc_engine_stretch_device(rc_engine *e, const float *d_in, size_t in_stride, size_t in_len,
+                             float *d_out, size_t out_stride, size_t out_cap, size_t *out_len,
+                             void *hip_stream);
+/* Sharded form for multi-GPU runs: only channels [ch_first, ch_first+ch_count) and output
+ * windows [win_first, win_first+win_count) of the same job; written at d_out offset 0.
+ * Hops are independent given the phase source, the one-hop overlap is recomputed locally. */
+int rc_engine_stretch_device_range(rc_engine *e, const float *d_in, size_t in_stride,
+                                   size_t in_len, uint32_t ch_first, uint32_t ch_count,
+                                   uint64_t win_first, uint64_t win_count, float *d_out,
+                                   size_t out_stride, size_t out_cap, void *hip_stream);
+
+/* ---- measurement ---------------------------------------------------------------------- */
+/* HIP-event time (ms) and hop count of the hop kernel launches of the last offline call;
+ * synchronises on the events. */
+int rc_engine_last_kernel_stats(rc_engine *e, float *kernel_ms, uint64_t *hops,
+                                uint32_t *launches);
+
+/* ---- single-hop entry points (ReFFT seam, used by parity tests) ----------------------- */
+/* ReFFT::forward_fft (src/fft.rs:50-61): host samples[window_len] -> host spectrum (re,im)*N */
+int rc_engine_forward_fft(rc_engine *e, const float *samples, float *out_reim);
+/* ReFFT::resynth (src/fft.rs:42-48) for hop `hop` of `channel` (phase key), no overlap-add:
+ * host samples[window_len] -> host out[window_len]. Applies the user kernel if configured. */
+int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float *samples,
+                      float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

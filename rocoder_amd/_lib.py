@@ -1,0 +1,117 @@
+"""ctypes loader for librocoder_hip.so — the C-ABI declared in include/rocoder_hip.h.
+
+The library is built in-tree by `rocoder_amd.build.build()` (hipcc, gfx950). There is no
+Python/CPU fallback: if the library is missing, loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librocoder_hip.so")
+
+RC_OK, RC_WOULD_BLOCK = 0, 1
+RC_EINVAL, RC_ENODEVICE, RC_EUNSUPPORTED, RC_ENOMEM, RC_EHIP, RC_ECAPACITY = -1, -2, -3, -4, -5, -6
+
+FREQ_KERNEL = C.CFUNCTYPE(C.c_int, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                          C.c_size_t, C.c_void_p)
+
+
+class rc_config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("window_len", C.c_uint32),
+        ("factor", C.c_float),
+        ("amplitude", C.c_float),
+        ("pitch_multiple", C.c_int32),
+        ("sample_rate", C.c_uint32),
+        ("channels", C.c_uint32),
+        ("buffer_secs", C.c_float),
+        ("seed", C.c_uint64),
+        ("device", C.c_int32),
+        ("max_batch_hops", C.c_uint32),
+        ("window", C.POINTER(C.c_float)),
+        ("kernel", FREQ_KERNEL),
+        ("kernel_user", C.c_void_p),
+        ("kernel_time_ms", C.c_uint64),
+    ]
+
+
+class rc_params(C.Structure):
+    _fields_ = [
+        ("window_len", C.c_uint32),
+        ("half_window_len", C.c_uint32),
+        ("samples_needed_per_window", C.c_uint64),
+        ("sample_step_len", C.c_uint32),
+        ("hops_per_window", C.c_uint32),
+        ("window_out_len", C.c_uint32),
+        ("corrected_amp_factor", C.c_float),
+        ("pitch_shifted_factor", C.c_float),
+    ]
+
+
+# every symbol include/rocoder_hip.h declares: name -> (restype, argtypes)
+_fp = C.POINTER(C.c_float)
+_sz = C.c_size_t
+_eng = C.c_void_p
+SYMBOLS = {
+    "rc_last_error": (C.c_char_p, []),
+    "rc_abi_version": (C.c_int, []),
+    "rc_device_count": (C.c_int, []),
+    "rc_derive_params": (C.c_int, [C.POINTER(rc_config), C.POINTER(rc_params)]),
+    "rc_offline_output_len": (_sz, [C.POINTER(rc_config), _sz]),
+    "rc_phase_key": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint64]),
+    "rc_phase_hash": (C.c_uint32, [C.c_uint64, C.c_uint32]),
+    "rc_engine_create": (C.c_int, [C.POINTER(rc_config), C.POINTER(_eng)]),
+    "rc_engine_destroy": (None, [_eng]),
+    "rc_engine_get_params": (C.c_int, [_eng, C.POINTER(rc_params)]),
+    "rc_engine_push_input": (C.c_int, [_eng, C.c_uint32, _fp, _sz]),
+    "rc_engine_close_input": (C.c_int, [_eng, C.c_uint32]),
+    "rc_engine_next_window": (C.c_int, [_eng, C.c_uint32, _fp, _sz, C.POINTER(_sz)]),
+    "rc_engine_is_done": (C.c_int, [_eng, C.c_uint32]),
+    "rc_engine_channel_bound": (_sz, [_eng]),
+    "rc_engine_stretch_host": (C.c_int, [_eng, C.POINTER(_fp), _sz, C.POINTER(_fp), _sz,
+                                         C.POINTER(_sz)]),
+    "rc_engine_stretch_device": (C.c_int, [_eng, C.c_void_p, _sz, _sz, C.c_void_p, _sz, _sz,
+                                           C.POINTER(_sz), C.c_void_p]),
+    "rc_engine_stretch_device_range": (C.c_int, [_eng, C.c_void_p, _sz, _sz, C.c_uint32, C.c_uint32,
+                                                 C.c_uint64, C.c_uint64, C.c_void_p, _sz, _sz,
+                                                 C.c_void_p]),
+    "rc_engine_last_kernel_stats": (C.c_int, [_eng, C.POINTER(C.c_float), C.POINTER(C.c_uint64),
+                                              C.POINTER(C.c_uint32)]),
+    "rc_engine_forward_fft": (C.c_int, [_eng, _fp, _fp]),
+    "rc_engine_resynth": (C.c_int, [_eng, C.c_uint32, C.c_uint64, _fp, _fp]),
+}
+
+_lib = None
+
+
+class RocoderError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rocoder_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib() -> C.CDLL:
+    """Load the engine library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise RocoderError(rc, lib().rc_last_error().decode(errors="replace"))
+    return rc

@@ -1,0 +1,731 @@
+// Host side of the C-ABI in include/rocoder_hip.h: parameter derivation, device tables,
+// launch planning, the streaming (Stretcher) seam and the user-kernel round trip.
+// There is deliberately no CPU compute path here: without a gfx950 device every compute
+// entry point fails with RC_ENODEVICE.
+#include "../../include/rocoder_hip.h"
+#include "rc_kernels.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define RC_HIP(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail(RC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+constexpr float kPiF32 = 3.14159274101257324219f;
+
+uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// windows::hanning (src/windows.rs:4-9), f32 operation order
+void hanning(size_t len, float *out) {
+    const float two_pi = kPiF32 * 2.0f;
+    for (size_t i = 0; i < len; i++)
+        out[i] = 0.5f - (cosf(((float)i * two_pi) / (float)(len - 1)) * 0.5f);
+}
+// crossfade::hanning_crossfade_compensation (src/crossfade.rs:4-10)
+void crossfade_comp(size_t len, float *out) {
+    const float two_pi = kPiF32 * 2.0f;
+    const float h = (1.0f + sqrtf(sqrtf(0.5f))) * 0.5f;
+    for (size_t i = 0; i < len; i++)
+        out[i] = 0.5f - ((1.0f - h) * cosf(((float)i * two_pi) / (float)(len - 1)));
+}
+
+int ilog2_exact(uint32_t v) {
+    if (!v || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1u << l) < v) l++;
+    return l;
+}
+
+// Stretcher::new derivation (src/stretcher.rs:40-56), f32 arithmetic as in the reference.
+int derive(const rc_config *c, rc_params *o) {
+    if (!c || c->struct_size != sizeof(rc_config)) return fail(RC_EINVAL, "bad rc_config size");
+    if (c->pitch_multiple == 0) return fail(RC_EINVAL, "pitch_multiple must be non-zero (src/stretcher.rs:40)");
+    if (c->pitch_multiple < -128 || c->pitch_multiple > 127)
+        return fail(RC_EINVAL, "pitch_multiple is an i8 in the reference");
+    if (c->pitch_multiple == -1)
+        return fail(RC_EINVAL, "pitch_multiple -1 panics in resampler::resample (src/resampler.rs:11)");
+    if (c->window_len < 2) return fail(RC_EINVAL, "window_len < 2");
+    if (c->channels == 0) return fail(RC_EINVAL, "channels == 0");
+    const float abs_p = (float)std::abs(c->pitch_multiple);
+    const float psf = c->pitch_multiple < 0 ? c->factor / abs_p : c->factor * abs_p;
+    const uint64_t S = c->pitch_multiple < 0
+                           ? (uint64_t)ceilf((float)c->window_len / abs_p)
+                           : (uint64_t)c->window_len * (uint64_t)std::abs(c->pitch_multiple);
+    const float amp = fmaxf(4.0f, psf / 4.0f) * c->amplitude;
+    const uint32_t H = c->window_len / 2;
+    const float stepf = (float)c->window_len / (psf * 2.0f);
+    if (!(stepf >= 1.0f))
+        return fail(RC_EINVAL, "sample_step_len == 0: the reference never terminates (src/stretcher.rs:55,105-106)");
+    if (stepf > (float)c->window_len)
+        return fail(RC_EINVAL, "sample_step_len > window_len: `len - step` underflows in the reference (src/stretcher.rs:105-106)");
+    o->window_len = c->window_len;
+    o->half_window_len = H;
+    o->samples_needed_per_window = S;
+    o->sample_step_len = (uint32_t)stepf;
+    const uint64_t tail = c->window_len - H;
+    o->hops_per_window = (uint32_t)((S + tail - 1) / tail);
+    if (c->pitch_multiple >= 1)
+        o->window_out_len = (uint32_t)((S + c->pitch_multiple - 1) / c->pitch_multiple);
+    else
+        o->window_out_len = (uint32_t)((S - 1) * (uint64_t)(-c->pitch_multiple));
+    o->corrected_amp_factor = amp;
+    o->pitch_shifted_factor = psf;
+    return RC_OK;
+}
+
+// windows emitted by an offline run on a closed channel of in_len samples
+uint64_t offline_windows(const rc_params &p, size_t in_len) {
+    const uint64_t kd = in_len >= p.window_len
+                            ? (uint64_t)(in_len - p.window_len) / p.sample_step_len + 1
+                            : 0;  // first hop whose window runs past the input
+    return kd / p.hops_per_window + 1;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return RC_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(RC_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return RC_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Channel {
+    std::vector<float> fifo;   // host samples from absolute index fifo_base
+    uint64_t fifo_base = 0;
+    bool closed = false;
+    uint64_t total_in = 0;     // samples ever pushed
+    uint64_t next_window = 0;  // next window index to COMPUTE
+    uint64_t windows_out = 0;  // windows handed to the caller
+    int64_t done_window = -1;  // window index whose hand-out sets is_done
+    std::deque<std::vector<float>> ready;
+};
+
+}  // namespace
+
+struct rc_engine {
+    rc_config cfg{};
+    rc_params par{};
+    int log2n = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool stats_valid = false;
+    uint64_t stats_hops = 0;
+    uint32_t stats_launches = 0;
+    float *d_window = nullptr, *d_env = nullptr;
+    float2 *d_wtab = nullptr, *d_rtab = nullptr;
+    uint64_t seed_mixed = 0;
+    int n_cu = 256;
+    std::vector<Channel> ch;
+    // scratch
+    DevBuf d_in, d_out, d_spec, d_ybuf, d_tail, d_hop_in, d_hop_out, d_xtail;
+    std::vector<float> h_spec, h_spec2, h_io;
+    bool tail_zeroed = false;
+};
+
+namespace {
+
+uint64_t now_ms(const rc_engine *e) {
+    if (e->cfg.kernel_time_ms) return e->cfg.kernel_time_ms;
+    using namespace std::chrono;
+    return (uint64_t)duration_cast<milliseconds>(system_clock::now().time_since_epoch()).count();
+}
+
+// Split hop_count hops per channel into runs so the launch fills the chip (>= ~2 workgroups
+// of 256 threads per CU) while keeping the one-hop recompute overhead of each run small.
+void plan_runs(const rc_engine *e, uint32_t n_channels, int64_t hop_count, uint32_t *runs,
+               uint32_t *run_len) {
+    int threads = 64;
+    size_t lds = 0;
+    rc::hop_geometry(e->log2n, &threads, &lds);
+    const size_t lds_cap = 160 * 1024;
+    uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(lds_cap / std::max<size_t>(lds, 1), 2048 / threads));
+    wg_per_cu = std::min<uint32_t>(wg_per_cu, 8);
+    const uint64_t target = (uint64_t)e->n_cu * wg_per_cu * 2;  // 2 waves of workgroups
+    uint64_t r = std::max<uint64_t>(1, target / std::max<uint32_t>(1, n_channels));
+    const int64_t min_run = 8;
+    r = std::min<uint64_t>(r, (uint64_t)std::max<int64_t>(1, hop_count / min_run));
+    r = std::max<uint64_t>(r, 1);
+    uint64_t len = ((uint64_t)hop_count + r - 1) / r;
+    r = ((uint64_t)hop_count + len - 1) / len;
+    *runs = (uint32_t)r;
+    *run_len = (uint32_t)len;
+}
+
+rc::HopParams base_params(const rc_engine *e) {
+    rc::HopParams p{};
+    p.window = e->d_window;
+    p.env = e->d_env;
+    p.wtab = e->d_wtab;
+    p.rtab = e->d_rtab;
+    p.amp = e->par.corrected_amp_factor;
+    p.step = e->par.sample_step_len;
+    p.pitch = (uint32_t)e->cfg.pitch_multiple;
+    p.seed_mixed = e->seed_mixed;
+    return p;
+}
+
+int check_gpu_path(const rc_engine *e) {
+    if (e->cfg.pitch_multiple < 1)
+        return fail(RC_EUNSUPPORTED, "negative pitch multiples (resample_slower, src/resampler.rs:20-35) are not on the GPU path yet");
+    return RC_OK;
+}
+
+// The core: compute hops [hop_first, hop_first+hop_count) of n_channels channels whose samples
+// live on the device, writing the decimated overlap-add at d_out (absolute F index out_origin).
+int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origin, int64_t in_len,
+             uint32_t ch_first, uint32_t n_channels, int64_t hop_first, int64_t hop_count,
+             float *d_out, size_t out_stride, int64_t out_origin, hipStream_t s, bool timed) {
+    if (hop_count <= 0 || n_channels == 0) return RC_OK;
+    rc::HopParams p = base_params(e);
+    p.x = d_in;
+    p.in_stride = in_stride;
+    p.in_origin = in_origin;
+    p.in_len = in_len;
+    p.out = d_out;
+    p.out_stride = out_stride;
+    p.out_origin = out_origin;
+    p.ch_first = ch_first;
+    p.n_channels = n_channels;
+    const uint32_t N = e->par.window_len, H = N / 2;
+    {
+        // Hops whose window runs past the end of the input read a zero-padded copy of the input
+        // tail (src/stretcher.rs:129-132: resize(n, 0.0)); the kernels never bounds-check.
+        const int64_t end_abs = in_origin + in_len;
+        const int64_t step = e->par.sample_step_len;
+        const int64_t k_last = hop_first + hop_count - 1;
+        int64_t k_t = end_abs >= (int64_t)N ? (end_abs - N) / step + 1 : 0;  // first short hop
+        const int64_t k_lo = (!e->cfg.kernel && hop_first > 0) ? hop_first - 1 : hop_first;
+        if (k_t < k_lo) k_t = k_lo;
+        p.xtail = d_in;
+        p.tail_stride = 0;
+        p.tail_origin = 0;
+        p.tail_hop_first = INT64_MAX;
+        if (k_t <= k_last) {
+            const int64_t t0 = k_t * step;
+            const size_t tail_len = (size_t)((k_last - k_t) * step + N);
+            const int64_t real = std::max<int64_t>(0, std::min<int64_t>(end_abs - t0, (int64_t)tail_len));
+            int rc = e->d_xtail.reserve((size_t)n_channels * tail_len * sizeof(float));
+            if (rc) return rc;
+            RC_HIP(hipMemsetAsync(e->d_xtail.p, 0, (size_t)n_channels * tail_len * sizeof(float), s));
+            if (real > 0)
+                RC_HIP(hipMemcpy2DAsync(e->d_xtail.p, tail_len * sizeof(float),
+                                        d_in + (t0 - in_origin),
+                                        std::max<size_t>(in_stride, (size_t)real) * sizeof(float),
+                                        (size_t)real * sizeof(float), n_channels,
+                                        hipMemcpyDeviceToDevice, s));
+            p.xtail = (const float *)e->d_xtail.p;
+            p.tail_stride = tail_len;
+            p.tail_origin = t0;
+            p.tail_hop_first = k_t;
+        }
+    }
+    if (!e->cfg.kernel) {
+        p.hop_first = hop_first;
+        p.hop_count = hop_count;
+        plan_runs(e, n_channels, hop_count, &p.runs_per_channel, &p.run_len);
+        if (timed) RC_HIP(hipEventRecord(e->ev0, s));
+        RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FUSED, p, s));
+        if (timed) {
+            RC_HIP(hipEventRecord(e->ev1, s));
+            e->stats_valid = true;
+            e->stats_hops = (uint64_t)hop_count * n_channels;
+            e->stats_launches = 1;
+        }
+        return RC_OK;
+    }
+    // ---- user frequency kernel: forward -> host apply() per hop -> resynth -> overlap-add.
+    // The overlap tail is carried in d_tail across chunks/calls (apply() may be stateful, so a
+    // hop is never recomputed). Hops are presented to apply() in the reference's order: windows
+    // outer, channels inner (src/stretcher_processor.rs:63-70), hops innermost.
+    const uint32_t hpw = e->par.hops_per_window;
+    const int64_t chunk_max = std::max<int64_t>(hpw, (int64_t)(((size_t)192 << 20) / ((size_t)N * 8 * n_channels)) / hpw * hpw);
+    int rc = e->d_tail.reserve((size_t)e->cfg.channels * H * sizeof(float));
+    if (rc) return rc;
+    if (!e->tail_zeroed) {
+        RC_HIP(hipMemsetAsync(e->d_tail.p, 0, (size_t)e->cfg.channels * H * sizeof(float), s));
+        e->tail_zeroed = true;
+    }
+    if (hop_first == 0)  // a fresh stream starts from H zeros (src/stretcher.rs:58-59)
+        RC_HIP(hipMemsetAsync((float *)e->d_tail.p + (size_t)ch_first * H, 0,
+                              (size_t)n_channels * H * sizeof(float), s));
+    for (int64_t k0 = hop_first; k0 < hop_first + hop_count; k0 += chunk_max) {
+        const int64_t kc = std::min<int64_t>(chunk_max, hop_first + hop_count - k0);
+        const size_t spec_floats = (size_t)n_channels * kc * N * 2;
+        if ((rc = e->d_spec.reserve(spec_floats * sizeof(float)))) return rc;
+        if ((rc = e->d_ybuf.reserve((size_t)n_channels * kc * N * sizeof(float)))) return rc;
+        p.spec = (float2 *)e->d_spec.p;
+        p.ybuf = (float *)e->d_ybuf.p;
+        p.hop_first = k0;
+        p.hop_count = kc;
+        plan_runs(e, n_channels, kc, &p.runs_per_channel, &p.run_len);
+        RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, p, s));
+        e->h_spec.resize(spec_floats);
+        e->h_spec2.resize((size_t)N * 2);
+        RC_HIP(hipMemcpyAsync(e->h_spec.data(), e->d_spec.p, spec_floats * sizeof(float),
+                              hipMemcpyDeviceToHost, s));
+        RC_HIP(hipStreamSynchronize(s));
+        for (int64_t w0 = 0; w0 < kc; w0 += hpw) {
+            for (uint32_t c = 0; c < n_channels; ++c) {
+                for (int64_t h = w0; h < std::min<int64_t>(w0 + hpw, kc); ++h) {
+                    float *sp = e->h_spec.data() + ((size_t)c * kc + h) * N * 2;
+                    // src/fft.rs:86-99: copy in, call apply(now_ms, bins), copy out
+                    const int krc = e->cfg.kernel(now_ms(e), sp, e->h_spec2.data(), N, e->cfg.kernel_user);
+                    if (krc == 0) memcpy(sp, e->h_spec2.data(), (size_t)N * 2 * sizeof(float));
+                    // non-zero == panic: keep the unmodified spectrum (src/fft.rs:100-106)
+                }
+            }
+        }
+        RC_HIP(hipMemcpyAsync(e->d_spec.p, e->h_spec.data(), spec_floats * sizeof(float),
+                              hipMemcpyHostToDevice, s));
+        RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, p, s));
+        rc::OlaParams o{};
+        o.ybuf = (const float *)e->d_ybuf.p;
+        o.tail = (float *)e->d_tail.p + (size_t)ch_first * H;
+        o.out = d_out;
+        o.out_stride = out_stride;
+        o.out_origin = out_origin;
+        o.env = e->d_env;
+        o.amp = e->par.corrected_amp_factor;
+        o.pitch = (uint32_t)e->cfg.pitch_multiple;
+        o.n_channels = n_channels;
+        o.hop_first = k0;
+        o.hop_count = kc;
+        o.log2n = (uint32_t)e->log2n;
+        RC_HIP(rc::launch_ola(o, s));
+        RC_HIP(hipStreamSynchronize(s));
+    }
+    return RC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rc_last_error(void) { return g_err.c_str(); }
+int rc_abi_version(void) { return RC_ABI_VERSION; }
+
+int rc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int rc_derive_params(const rc_config *cfg, rc_params *out) {
+    if (!out) return fail(RC_EINVAL, "null out");
+    return derive(cfg, out);
+}
+
+size_t rc_offline_output_len(const rc_config *cfg, size_t in_len) {
+    rc_params p;
+    if (derive(cfg, &p) != RC_OK) return 0;
+    return (size_t)(offline_windows(p, in_len) * p.window_out_len);
+}
+
+uint64_t rc_phase_key(uint64_t seed, uint32_t channel, uint64_t hop) {
+    const uint64_t ctr = ((uint64_t)channel << 40) | (hop & 0xFFFFFFFFFFull);
+    return mix64(mix64(seed) ^ ctr);
+}
+
+uint32_t rc_phase_hash(uint64_t key, uint32_t bin) {
+    uint32_t x = bin * ((uint32_t)(key >> 32) | 1u) + (uint32_t)key;
+    x ^= x >> 16;
+    x *= 0x21F0AAADu;
+    x ^= x >> 15;
+    x *= 0x735A2D97u;
+    x ^= x >> 15;
+    return x;
+}
+
+int rc_engine_create(const rc_config *cfg, rc_engine **out) {
+    if (!out) return fail(RC_EINVAL, "null out");
+    *out = nullptr;
+    rc_params par;
+    int rc = derive(cfg, &par);
+    if (rc) return rc;
+    const int log2n = ilog2_exact(cfg->window_len);
+    if (log2n < 5 || log2n > 14)
+        return fail(RC_EUNSUPPORTED, "window_len %u: the GPU path supports powers of two in [32, 16384]", cfg->window_len);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return fail(RC_ENODEVICE, "no HIP device available (this library has no CPU fallback)");
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(RC_EINVAL, "device %d out of range", cfg->device);
+    RC_HIP(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    RC_HIP(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RC_ENODEVICE, "device %d is %s; this library is built for gfx950 only", cfg->device, prop.gcnArchName);
+    rc_engine *e = new (std::nothrow) rc_engine();
+    if (!e) return fail(RC_ENOMEM, "out of host memory");
+    e->cfg = *cfg;
+    e->cfg.window = nullptr;
+    e->par = par;
+    e->log2n = log2n;
+    e->device = cfg->device;
+    e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e->seed_mixed = mix64(cfg->seed);
+    e->ch.resize(cfg->channels);
+    const uint32_t N = cfg->window_len, M = N / 2, H = N / 2;
+    std::vector<float> w(N), env(H);
+    if (cfg->window) memcpy(w.data(), cfg->window, N * sizeof(float));
+    else hanning(N, w.data());                    // src/main.rs:131
+    crossfade_comp(H, env.data());                // src/stretcher.rs:56
+    std::vector<float2> wtab(std::max<uint32_t>(1, M / 2)), rtab(M / 4 + 1);
+    for (uint32_t k = 0; k < M / 2; ++k) {        // twiddles in f64, rounded to f32 (as rustfft does)
+        const double a = -2.0 * M_PI * (double)k / (double)M;
+        wtab[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    for (uint32_t j = 0; j <= M / 4; ++j) {
+        const double a = -2.0 * M_PI * (double)j / (double)N;
+        rtab[j] = make_float2((float)cos(a), (float)sin(a));
+    }
+    auto cleanup = [&](int code) {
+        rc_engine_destroy(e);
+        return code;
+    };
+#define RC_HIP_C(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return cleanup(fail(RC_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)));       \
+    } while (0)
+    RC_HIP_C(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    RC_HIP_C(hipEventCreate(&e->ev0));
+    RC_HIP_C(hipEventCreate(&e->ev1));
+    RC_HIP_C(hipMalloc((void **)&e->d_window, N * sizeof(float)));
+    RC_HIP_C(hipMalloc((void **)&e->d_env, H * sizeof(float)));
+    RC_HIP_C(hipMalloc((void **)&e->d_wtab, wtab.size() * sizeof(float2)));
+    RC_HIP_C(hipMalloc((void **)&e->d_rtab, rtab.size() * sizeof(float2)));
+    RC_HIP_C(hipMemcpy(e->d_window, w.data(), N * sizeof(float), hipMemcpyHostToDevice));
+    RC_HIP_C(hipMemcpy(e->d_env, env.data(), H * sizeof(float), hipMemcpyHostToDevice));
+    RC_HIP_C(hipMemcpy(e->d_wtab, wtab.data(), wtab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    RC_HIP_C(hipMemcpy(e->d_rtab, rtab.data(), rtab.size() * sizeof(float2), hipMemcpyHostToDevice));
+#undef RC_HIP_C
+    *out = e;
+    return RC_OK;
+}
+
+void rc_engine_destroy(rc_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->d_window) (void)hipFree(e->d_window);
+    if (e->d_env) (void)hipFree(e->d_env);
+    if (e->d_wtab) (void)hipFree(e->d_wtab);
+    if (e->d_rtab) (void)hipFree(e->d_rtab);
+    e->d_in.release();
+    e->d_out.release();
+    e->d_spec.release();
+    e->d_ybuf.release();
+    e->d_tail.release();
+    e->d_hop_in.release();
+    e->d_hop_out.release();
+    e->d_xtail.release();
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int rc_engine_get_params(const rc_engine *e, rc_params *out) {
+    if (!e || !out) return fail(RC_EINVAL, "null argument");
+    *out = e->par;
+    return RC_OK;
+}
+
+size_t rc_engine_channel_bound(const rc_engine *e) {
+    if (!e) return 0;
+    // src/stretcher.rs:82-85
+    const float v = ((float)e->par.window_len / (float)e->cfg.sample_rate) / e->cfg.buffer_secs;
+    return (size_t)ceilf(v);
+}
+
+int rc_engine_push_input(rc_engine *e, uint32_t channel, const float *samples, size_t n) {
+    if (!e || channel >= e->ch.size() || (!samples && n)) return fail(RC_EINVAL, "bad argument");
+    Channel &c = e->ch[channel];
+    if (c.closed) return fail(RC_EINVAL, "channel %u is closed", channel);
+    c.fifo.insert(c.fifo.end(), samples, samples + n);
+    c.total_in += n;
+    return RC_OK;
+}
+
+int rc_engine_close_input(rc_engine *e, uint32_t channel) {
+    if (!e || channel >= e->ch.size()) return fail(RC_EINVAL, "bad argument");
+    e->ch[channel].closed = true;
+    return RC_OK;
+}
+
+int rc_engine_is_done(const rc_engine *e, uint32_t channel) {
+    if (!e || channel >= e->ch.size()) return fail(RC_EINVAL, "bad argument");
+    const Channel &c = e->ch[channel];
+    return (c.done_window >= 0 && (int64_t)c.windows_out > c.done_window) ? 1 : 0;
+}
+
+int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out_cap, size_t *n_out) {
+    if (!e || channel >= e->ch.size() || !out) return fail(RC_EINVAL, "bad argument");
+    int rc = check_gpu_path(e);
+    if (rc) return rc;
+    Channel &c = e->ch[channel];
+    const rc_params &P = e->par;
+    const uint32_t N = P.window_len, hpw = P.hops_per_window, step = P.sample_step_len;
+    const uint32_t wout = P.window_out_len;
+    if (out_cap < wout) return fail(RC_ECAPACITY, "out_cap %zu < window_out_len %u", out_cap, wout);
+    if (c.ready.empty()) {
+        // how many whole windows can be computed now?
+        //  hop h needs samples [h*step, h*step+N); on a closed channel the shortfall is zero
+        //  padded and `done` is raised at the first short hop (src/stretcher.rs:123-135).
+        const uint64_t k0 = c.next_window * hpw;
+        uint64_t nwin = 0;
+        if (c.closed) {
+            if (c.done_window >= 0 && (int64_t)c.next_window > c.done_window)
+                return fail(RC_EINVAL, "next_window called after is_done (src/stretcher_processor.rs:64-68 never does)");
+            const uint64_t kd = c.total_in >= N ? (c.total_in - N) / step + 1 : 0;
+            const uint64_t last_win = kd / hpw;  // window containing the first short hop
+            nwin = last_win + 1 - c.next_window;
+            c.done_window = (int64_t)last_win;
+        } else {
+            if (c.total_in < N) return RC_WOULD_BLOCK;
+            const uint64_t full_hops = (c.total_in - N) / step + 1;  // hops 0..full_hops-1 are complete
+            if (full_hops < k0 + hpw) return RC_WOULD_BLOCK;
+            nwin = (full_hops - k0) / hpw;
+        }
+        uint64_t max_hops = e->cfg.max_batch_hops ? e->cfg.max_batch_hops : 2048;
+        // live mode: never run further ahead than the bounded output queue would
+        // (src/stretcher_processor.rs:34, src/stretcher.rs:82-85) unless the whole input is known
+        uint64_t max_win = std::max<uint64_t>(1, max_hops / hpw);
+        if (!c.closed) max_win = std::min<uint64_t>(max_win, std::max<size_t>(1, rc_engine_channel_bound(e)));
+        nwin = std::min<uint64_t>(nwin, max_win);
+        const uint64_t hop_count = nwin * hpw;
+        // input span: from the hop before k0 (its tail is recomputed) unless a user kernel
+        // carries the tail on the device
+        const bool recompute = !e->cfg.kernel && k0 > 0;
+        const uint64_t span_lo = (recompute ? k0 - 1 : k0) * (uint64_t)step;
+        const uint64_t span_hi = std::min<uint64_t>(c.total_in, (k0 + hop_count - 1) * (uint64_t)step + N);
+        if (span_lo < c.fifo_base) return fail(RC_EINVAL, "internal: input history dropped");
+        const size_t span = span_hi > span_lo ? (size_t)(span_hi - span_lo) : 0;
+        RC_HIP(hipSetDevice(e->device));
+        if ((rc = e->d_in.reserve(std::max<size_t>(span, 1) * sizeof(float)))) return rc;
+        if ((rc = e->d_out.reserve((size_t)nwin * wout * sizeof(float)))) return rc;
+        if (span)
+            RC_HIP(hipMemcpyAsync(e->d_in.p, c.fifo.data() + (span_lo - c.fifo_base), span * sizeof(float),
+                                  hipMemcpyHostToDevice, e->stream));
+        rc = run_hops(e, (const float *)e->d_in.p, 0, (int64_t)span_lo, (int64_t)span, channel, 1,
+                      (int64_t)k0, (int64_t)hop_count, (float *)e->d_out.p, 0,
+                      (int64_t)(c.next_window * wout), e->stream, false);
+        if (rc) return rc;
+        e->h_io.resize((size_t)nwin * wout);
+        RC_HIP(hipMemcpyAsync(e->h_io.data(), e->d_out.p, (size_t)nwin * wout * sizeof(float),
+                              hipMemcpyDeviceToHost, e->stream));
+        RC_HIP(hipStreamSynchronize(e->stream));
+        for (uint64_t w = 0; w < nwin; ++w)
+            c.ready.emplace_back(e->h_io.begin() + w * wout, e->h_io.begin() + (w + 1) * wout);
+        c.next_window += nwin;
+        // drop input no later hop needs: keep from (next hop - 1) * step
+        const uint64_t keep_from = (c.next_window * hpw > 0 ? c.next_window * hpw - 1 : 0) * (uint64_t)step;
+        if (keep_from > c.fifo_base) {
+            const uint64_t drop = std::min<uint64_t>(keep_from - c.fifo_base, c.fifo.size());
+            c.fifo.erase(c.fifo.begin(), c.fifo.begin() + drop);
+            c.fifo_base += drop;
+        }
+    }
+    std::vector<float> &w = c.ready.front();
+    memcpy(out, w.data(), w.size() * sizeof(float));
+    if (n_out) *n_out = w.size();
+    c.ready.pop_front();
+    c.windows_out++;
+    return RC_OK;
+}
+
+int rc_engine_stretch_device_range(rc_engine *e, const float *d_in, size_t in_stride, size_t in_len,
+                                   uint32_t ch_first, uint32_t ch_count, uint64_t win_first,
+                                   uint64_t win_count, float *d_out, size_t out_stride,
+                                   size_t out_cap, void *hip_stream) {
+    if (!e || !d_out || (!d_in && in_len)) return fail(RC_EINVAL, "null argument");
+    int rc = check_gpu_path(e);
+    if (rc) return rc;
+    if (ch_first + ch_count > e->cfg.channels) return fail(RC_EINVAL, "channel range out of bounds");
+    const uint64_t total_win = offline_windows(e->par, in_len);
+    if (win_first + win_count > total_win) return fail(RC_EINVAL, "window range out of bounds");
+    const uint64_t wout = e->par.window_out_len;
+    if (out_cap < win_count * wout) return fail(RC_ECAPACITY, "out_cap %zu < %llu", out_cap, (unsigned long long)(win_count * wout));
+    if (e->cfg.kernel && win_first != 0 && !e->tail_zeroed)
+        return fail(RC_EINVAL, "a user kernel carries the overlap tail: ranges must be issued in order from window 0");
+    RC_HIP(hipSetDevice(e->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+    const uint32_t hpw = e->par.hops_per_window;
+    return run_hops(e, d_in + (size_t)ch_first * in_stride, in_stride, 0, (int64_t)in_len, ch_first,
+                    ch_count, (int64_t)(win_first * hpw), (int64_t)(win_count * hpw), d_out, out_stride,
+                    (int64_t)(win_first * wout), s, true);
+}
+
+int rc_engine_stretch_device(rc_engine *e, const float *d_in, size_t in_stride, size_t in_len,
+                             float *d_out, size_t out_stride, size_t out_cap, size_t *out_len,
+                             void *hip_stream) {
+    if (!e) return fail(RC_EINVAL, "null engine");
+    const uint64_t total_win = offline_windows(e->par, in_len);
+    int rc = rc_engine_stretch_device_range(e, d_in, in_stride, in_len, 0, e->cfg.channels, 0,
+                                            total_win, d_out, out_stride, out_cap, hip_stream);
+    if (rc == RC_OK && out_len) *out_len = (size_t)(total_win * e->par.window_out_len);
+    return rc;
+}
+
+int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, float *const *out,
+                           size_t out_cap, size_t *out_len) {
+    if (!e || !in || !out) return fail(RC_EINVAL, "null argument");
+    int rc = check_gpu_path(e);
+    if (rc) return rc;
+    const uint32_t C = e->cfg.channels;
+    const uint64_t total_win = offline_windows(e->par, in_len);
+    const size_t n_out = (size_t)(total_win * e->par.window_out_len);
+    if (out_cap < n_out) return fail(RC_ECAPACITY, "out_cap %zu < %zu", out_cap, n_out);
+    RC_HIP(hipSetDevice(e->device));
+    const size_t in_stride = std::max<size_t>(in_len, 1);
+    if ((rc = e->d_in.reserve((size_t)C * in_stride * sizeof(float)))) return rc;
+    if ((rc = e->d_out.reserve((size_t)C * std::max<size_t>(n_out, 1) * sizeof(float)))) return rc;
+    for (uint32_t c = 0; c < C; ++c)
+        if (in_len)
+            RC_HIP(hipMemcpyAsync((float *)e->d_in.p + (size_t)c * in_stride, in[c], in_len * sizeof(float),
+                                  hipMemcpyHostToDevice, e->stream));
+    rc = rc_engine_stretch_device_range(e, (const float *)e->d_in.p, in_stride, in_len, 0, C, 0, total_win,
+                                        (float *)e->d_out.p, n_out, n_out, e->stream);
+    if (rc) return rc;
+    for (uint32_t c = 0; c < C; ++c)
+        RC_HIP(hipMemcpyAsync(out[c], (float *)e->d_out.p + (size_t)c * n_out, n_out * sizeof(float),
+                              hipMemcpyDeviceToHost, e->stream));
+    RC_HIP(hipStreamSynchronize(e->stream));
+    if (out_len) *out_len = n_out;
+    return RC_OK;
+}
+
+int rc_engine_last_kernel_stats(rc_engine *e, float *kernel_ms, uint64_t *hops, uint32_t *launches) {
+    if (!e) return fail(RC_EINVAL, "null engine");
+    if (!e->stats_valid) return fail(RC_EINVAL, "no timed launch recorded yet");
+    RC_HIP(hipEventSynchronize(e->ev1));
+    float ms = 0.f;
+    RC_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    if (kernel_ms) *kernel_ms = ms;
+    if (hops) *hops = e->stats_hops;
+    if (launches) *launches = e->stats_launches;
+    return RC_OK;
+}
+
+int rc_engine_forward_fft(rc_engine *e, const float *samples, float *out_reim) {
+    if (!e || !samples || !out_reim) return fail(RC_EINVAL, "null argument");
+    const uint32_t N = e->par.window_len;
+    RC_HIP(hipSetDevice(e->device));
+    int rc;
+    if ((rc = e->d_hop_in.reserve(N * sizeof(float)))) return rc;
+    if ((rc = e->d_hop_out.reserve((size_t)N * 2 * sizeof(float)))) return rc;
+    RC_HIP(hipMemcpyAsync(e->d_hop_in.p, samples, N * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    rc::HopParams p = base_params(e);
+    p.x = (const float *)e->d_hop_in.p;
+    p.in_len = N;
+    p.xtail = p.x;
+    p.tail_hop_first = INT64_MAX;
+    p.n_channels = 1;
+    p.hop_first = 0;
+    p.hop_count = 1;
+    p.runs_per_channel = 1;
+    p.run_len = 1;
+    p.step = 1;
+    p.spec = (float2 *)e->d_hop_out.p;
+    RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, p, e->stream));
+    RC_HIP(hipMemcpyAsync(out_reim, e->d_hop_out.p, (size_t)N * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    RC_HIP(hipStreamSynchronize(e->stream));
+    return RC_OK;
+}
+
+int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float *samples, float *out) {
+    if (!e || !samples || !out) return fail(RC_EINVAL, "null argument");
+    const uint32_t N = e->par.window_len;
+    RC_HIP(hipSetDevice(e->device));
+    int rc;
+    if ((rc = e->d_hop_in.reserve(N * sizeof(float)))) return rc;
+    if ((rc = e->d_hop_out.reserve((size_t)N * 2 * sizeof(float)))) return rc;
+    if ((rc = e->d_ybuf.reserve((size_t)N * sizeof(float)))) return rc;
+    RC_HIP(hipMemcpyAsync(e->d_hop_in.p, samples, N * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    rc::HopParams p = base_params(e);
+    p.x = (const float *)e->d_hop_in.p;
+    // present the window as hop `hop` of a stream whose sample 0 is hop*step
+    p.in_origin = (int64_t)hop * p.step;
+    p.in_len = N;
+    p.xtail = p.x;
+    p.tail_hop_first = INT64_MAX;
+    p.ch_first = channel;
+    p.n_channels = 1;
+    p.hop_first = (int64_t)hop;
+    p.hop_count = 1;
+    p.runs_per_channel = 1;
+    p.run_len = 1;
+    p.spec = (float2 *)e->d_hop_out.p;
+    p.ybuf = (float *)e->d_ybuf.p;
+    RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, p, e->stream));
+    if (e->cfg.kernel) {
+        e->h_spec.resize((size_t)N * 2);
+        e->h_spec2.resize((size_t)N * 2);
+        RC_HIP(hipMemcpyAsync(e->h_spec.data(), e->d_hop_out.p, (size_t)N * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        RC_HIP(hipStreamSynchronize(e->stream));
+        if (e->cfg.kernel(now_ms(e), e->h_spec.data(), e->h_spec2.data(), N, e->cfg.kernel_user) == 0)
+            RC_HIP(hipMemcpyAsync(e->d_hop_out.p, e->h_spec2.data(), (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    }
+    RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, p, e->stream));
+    RC_HIP(hipMemcpyAsync(out, e->d_ybuf.p, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    RC_HIP(hipStreamSynchronize(e->stream));
+    return RC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// Internal interface between the host engine (rc_engine.cpp) and the gfx950 kernels
+// (rc_kernels.hip). Not part of the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rc {
+
+// One launch = channels [0, n_channels) x hops [hop_first, hop_first + hop_count), cut into
+// `runs_per_channel` contiguous runs of `run_len` hops; one workgroup walks one run.
+struct HopParams {
+    const float *x;        // channel c at x + c * in_stride; x[0] is absolute sample `in_origin`
+    size_t in_stride;
+    int64_t in_origin;
+    int64_t in_len;        // samples valid at x (absolute index in_origin + in_len is the end)
+    // hops k >= tail_hop_first read a zero-padded copy instead (windows running past the end of
+    // the closed input): channel c at xtail + c * tail_stride, xtail[0] is absolute tail_origin
+    const float *xtail;
+    size_t tail_stride;
+    int64_t tail_origin;
+    int64_t tail_hop_first;
+    float *out;            // F (decimated overlap-add), channel c at out + c * out_stride
+    size_t out_stride;
+    int64_t out_origin;    // absolute F index of out[0]
+    const float *window;   // [N]
+    const float *env;      // [N/2] hanning_crossfade_compensation
+    const float2 *wtab;    // [M/2]   exp(-2 pi i k / M), M = N/2
+    const float2 *rtab;    // [M/4+1] exp(-2 pi i j / N)
+    float amp;             // corrected_amp_factor
+    uint32_t step;         // sample_step_len
+    uint32_t pitch;        // pitch_multiple >= 1
+    uint64_t seed_mixed;   // mix64(seed)
+    uint32_t ch_first;     // absolute channel index of local channel 0 (phase source)
+    uint32_t n_channels;
+    int64_t hop_first;
+    int64_t hop_count;
+    uint32_t runs_per_channel;
+    uint32_t run_len;
+    // spectrum modes (user-kernel path)
+    float2 *spec;          // [n_channels][hop_count][N] natural-order spectrum
+    float *ybuf;           // [n_channels][hop_count][N] windowed resynthesis output y_k
+};
+
+struct OlaParams {
+    const float *ybuf;     // [n_channels][hop_count][N]
+    float *tail;           // [n_channels][H] carried y_{k-1}[H..] (read, then updated)
+    float *out;
+    size_t out_stride;
+    int64_t out_origin;
+    const float *env;
+    float amp;
+    uint32_t pitch;
+    uint32_t n_channels;
+    int64_t hop_first;
+    int64_t hop_count;
+    uint32_t log2n;
+};
+
+enum HopMode { MODE_FUSED = 0, MODE_FORWARD = 1, MODE_RESYNTH = 2 };
+
+// Geometry chosen by the kernels for a window length (threads per workgroup, LDS bytes).
+bool hop_geometry(int log2n, int *threads, size_t *lds_bytes);
+// Launchers. Return hipSuccess or the launch error. log2n in [5, 14].
+hipError_t launch_hop(int log2n, HopMode mode, const HopParams &p, hipStream_t s);
+hipError_t launch_ola(const OlaParams &p, hipStream_t s);
+
+}  // namespace rc

@@ -1,0 +1,602 @@
+// gfx950 (MI355X / CDNA4) kernels of the rocoder stretch hot path.
+//
+// One workgroup owns a contiguous run of hops of one channel and, per hop k, computes
+//   a_k[n] = x[k*step+n] * w[n]                       (src/fft.rs:51-55)
+//   X_k    = DFT_N(a_k)                                (src/fft.rs:59)      real->complex, N/2-pt
+//   Z_k[j] = |X_k[j]| * e^{i theta(seed,c,k,j)}        (src/fft.rs:65-68)   all N bins drawn
+//   y_k[n] = Re(IDFT_N(Z_k))[n] / N * w[n]             (src/fft.rs:69-73)   complex->real, N/2-pt
+//   O[kH+i] = (y_k[i] + y_{k-1}[H+i]) * env[i] * amp   (src/stretcher.rs:96-103)
+//   F[t]    = O[t*p]                                   (src/stretcher.rs:108-111, resampler.rs:15-18)
+//
+// Layout of one hop inside the workgroup (M = N/2 complex points, T threads, P = M/T
+// register-resident points per thread):
+//   * the N/2-point FFT runs as bit-group passes: each pass transforms up to log2(P) index bits
+//     entirely in registers (radix-2 butterflies with compile-time 32nd roots x one per-thread
+//     base twiddle per stage), passes exchange through LDS (padded 1 complex per 32: conflict-free
+//     ds_read/write_b64 for every pass layout); forward is DIF (natural in, bit-reversed out),
+//     inverse is the mirrored DIT, so no reordering pass exists;
+//   * the real<->complex split, magnitude, random phasors and the Hermitian fold happen on the
+//     bit-reversed spectrum in LDS, a "quad" {j, j+M/2, M/2-j, M-j} per slot;
+//   * the window multiply and the two-term overlap-add stay in registers: a thread's tail samples
+//     of hop k line up with its head samples of hop k+1, so the run carries y_{k-1}[H..] in VGPRs
+//     and the first hop of a run is recomputed (phases are a pure function of (seed,c,k,j)).
+// No MFMA: this is an FFT/SFU/LDS-bound path, not a contraction.
+#include "rc_kernels.h"
+
+namespace rc {
+namespace {
+
+// exp(-2 pi i c / 32), c = 0..15
+__device__ constexpr float W32_RE[16] = {
+    1.f, 0.980785251f, 0.923879504f, 0.831469595f, 0.707106769f, 0.555570245f, 0.382683426f,
+    0.195090324f, 0.f, -0.195090324f, -0.382683426f, -0.555570245f, -0.707106769f, -0.831469595f,
+    -0.923879504f, -0.980785251f};
+__device__ constexpr float W32_IM[16] = {
+    -0.f, -0.195090324f, -0.382683426f, -0.555570245f, -0.707106769f, -0.831469595f,
+    -0.923879504f, -0.980785251f, -1.f, -0.980785251f, -0.923879504f, -0.831469595f,
+    -0.707106769f, -0.555570245f, -0.382683426f, -0.195090324f};
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }
+
+template <int LOG2N>
+struct Geo {
+    static constexpr int m = LOG2N - 1;        // log2 of complex length
+    static constexpr int M = 1 << m;           // complex points
+    static constexpr int N = 2 * M;            // window length
+    static constexpr int T = cmax(M / 32, cmin(64, M / 4));  // threads per workgroup
+    static constexpr int P = M / T;            // points per thread
+    static constexpr int B = clog2(P);         // index bits per pass
+    static constexpr int LDS_FLOAT2 = M + (M >> 5) + 1;
+    static constexpr int LO0 = m - B;          // register layout of the first/last (global) pass
+    static constexpr int QN = cmax(1, (M / 4) / T);  // middle-stage quad slots per thread
+};
+
+// pass k transforms absolute index bits [lo_of(prev), prev-1]; its registers hold bits
+// [lor_of(prev), lor_of(prev)+B-1]
+template <class G> constexpr int lo_of(int prev) { return cmax(0, prev - G::B); }
+template <class G> constexpr int lor_of(int prev) {
+    return (prev - lo_of<G>(prev) == G::B) ? lo_of<G>(prev) : 0;
+}
+template <class G> constexpr int last_lor(int prev) {
+    return lo_of<G>(prev) == 0 ? lor_of<G>(prev) : last_lor<G>(lo_of<G>(prev));
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+constexpr int pad_idx(int n) { return n + (n >> 5); }
+
+template <int B, int LO>
+constexpr int pos_of(int tid, int q) {
+    return ((tid >> LO) << (LO + B)) | (q << LO) | (tid & ((1 << LO) - 1));
+}
+// The index fields (l, q, u) occupy disjoint bit ranges, so the padded LDS index splits into a
+// per-thread base (one VGPR, live across the run) plus a compile-time offset per register q
+// (folded into the ds_read/ds_write immediate): pad(pos(tid,q)) = pad(pos(tid,0)) + pad(pos(0,q)).
+template <int B, int LO>
+constexpr int lds_reg_off(int q) { return pad_idx(pos_of<B, LO>(0, q)); }
+
+template <class G, int LO>
+__device__ __forceinline__ void lds_store(const float2 (&v)[G::P], float2 *lds, int base) {
+#pragma unroll
+    for (int q = 0; q < G::P; ++q) lds[base + lds_reg_off<G::B, LO>(q)] = v[q];
+}
+template <class G, int LO>
+__device__ __forceinline__ void lds_load(float2 (&v)[G::P], const float2 *lds, int base) {
+#pragma unroll
+    for (int q = 0; q < G::P; ++q) v[q] = lds[base + lds_reg_off<G::B, LO>(q)];
+}
+
+// Opaque copies: stop LICM from hoisting per-hop recomputable values (twiddle products, table
+// loads, slot addresses) out of the hop loop into hundreds of live VGPRs.
+__device__ __forceinline__ void opaque(float2 &x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); }
+__device__ __forceinline__ void opaque(int &x) { asm volatile("" : "+v"(x)); }
+
+// Per-thread state that is worth keeping in registers across the hops of a run.
+template <class G>
+struct ThreadCtx {
+    int tid;
+    int lb[G::m + 1];  // padded LDS base index per register layout LO (unused entries fold away)
+};
+template <class G, int LO>
+__device__ __forceinline__ void fill_lds_bases(ThreadCtx<G> &c) {
+    if constexpr (LO >= 0) {
+        c.lb[LO] = (LO + G::B <= G::m) ? pad_idx(pos_of<G::B, LO>(c.tid, 0)) : 0;
+        fill_lds_bases<G, LO - 1>(c);
+    }
+}
+
+// One in-register pass: radix-2 stages on absolute bits S_LO..S_HI, register bit r = s - LOR.
+// Forward (DIF):  a' = a + b,           b' = (a - b) w
+// Inverse (DIT):  a' = a + conj(w) b,   b' = a - conj(w) b      (conjugate transpose of DIF)
+// w = exp(-2 pi i (n mod 2^s) / 2^(s+1)) = base_s(thread) * W32^(c * 16 >> r)
+template <class G, int LOR, int S_LO, int S_HI, bool INV>
+__device__ __forceinline__ void run_pass(float2 (&v)[G::P], int tid,
+                                         const float2 *__restrict__ wtab) {
+    const int l = tid & ((1 << LOR) - 1);
+#pragma unroll
+    for (int si = 0; si <= S_HI - S_LO; ++si) {
+        const int s = INV ? (S_LO + si) : (S_HI - si);
+        const int r = s - LOR;
+        const int half = 1 << r;
+        float2 base = make_float2(1.f, 0.f);
+        if (LOR > 0) {
+            base = wtab[l << (G::m - 1 - s)];
+            opaque(base);
+        }
+#pragma unroll
+        for (int q0 = 0; q0 < G::P; ++q0) {
+            if (q0 & half) continue;
+            const int q1 = q0 | half;
+            const int c = q0 & (half - 1);
+            const int kidx = c * (16 >> r);
+            const float2 a = v[q0], b = v[q1];
+            if (LOR == 0 && c == 0) {  // w = 1
+                v[q0] = make_float2(a.x + b.x, a.y + b.y);
+                v[q1] = make_float2(a.x - b.x, a.y - b.y);
+            } else if (LOR == 0 && kidx == 8) {  // w = -i
+                if (!INV) {
+                    v[q0] = make_float2(a.x + b.x, a.y + b.y);
+                    const float dx = a.x - b.x, dy = a.y - b.y;
+                    v[q1] = make_float2(dy, -dx);  // d * (-i)
+                } else {
+                    const float tx = -b.y, ty = b.x;  // (+i) * b
+                    v[q0] = make_float2(a.x + tx, a.y + ty);
+                    v[q1] = make_float2(a.x - tx, a.y - ty);
+                }
+            } else {
+                float2 w;
+                if (c == 0) w = base;
+                else if (LOR == 0) w = make_float2(W32_RE[kidx], W32_IM[kidx]);
+                else if (kidx == 8) w = make_float2(base.y, -base.x);
+                else w = cmul(base, make_float2(W32_RE[kidx], W32_IM[kidx]));
+                if (!INV) {
+                    v[q0] = make_float2(a.x + b.x, a.y + b.y);
+                    const float dx = a.x - b.x, dy = a.y - b.y;
+                    v[q1] = make_float2(dx * w.x - dy * w.y, dx * w.y + dy * w.x);
+                } else {
+                    // a + conj(w) b in 4 FMAs, a - conj(w) b = 2a - (a + conj(w) b) in 2
+                    const float rx = fmaf(w.y, b.y, fmaf(w.x, b.x, a.x));
+                    const float ry = fmaf(-w.y, b.x, fmaf(w.x, b.y, a.y));
+                    v[q0] = make_float2(rx, ry);
+                    v[q1] = make_float2(fmaf(2.f, a.x, -rx), fmaf(2.f, a.y, -ry));
+                }
+            }
+        }
+    }
+}
+
+// forward passes, high bits first. On return v is in register layout last_lor.
+template <class G, int PREV, int PREV_LOR, bool FIRST>
+__device__ __forceinline__ void forward_passes(float2 (&v)[G::P], float2 *lds,
+                                               const ThreadCtx<G> &c,
+                                               const float2 *__restrict__ wtab) {
+    if constexpr (PREV > 0) {
+        constexpr int lo = lo_of<G>(PREV);
+        constexpr int LOR = lor_of<G>(PREV);
+        if constexpr (!FIRST) {
+            lds_store<G, PREV_LOR>(v, lds, c.lb[PREV_LOR]);
+            __syncthreads();
+            lds_load<G, LOR>(v, lds, c.lb[LOR]);
+            __syncthreads();
+        }
+        run_pass<G, LOR, lo, PREV - 1, false>(v, c.tid, wtab);
+        forward_passes<G, lo, LOR, false>(v, lds, c, wtab);
+    }
+}
+
+// inverse passes, low bits first. Expects v loaded in layout last_lor; returns layout LO0.
+template <class G, int PREV>
+__device__ __forceinline__ void inverse_passes(float2 (&v)[G::P], float2 *lds,
+                                               const ThreadCtx<G> &c,
+                                               const float2 *__restrict__ wtab) {
+    if constexpr (PREV > 0) {
+        constexpr int lo = lo_of<G>(PREV);
+        constexpr int LOR = lor_of<G>(PREV);
+        if constexpr (lo > 0) {
+            inverse_passes<G, lo>(v, lds, c, wtab);
+            constexpr int LOR_DEEPER = lor_of<G>(lo);
+            lds_store<G, LOR_DEEPER>(v, lds, c.lb[LOR_DEEPER]);
+            __syncthreads();
+            lds_load<G, LOR>(v, lds, c.lb[LOR]);
+            __syncthreads();
+        }
+        run_pass<G, LOR, lo, PREV - 1, true>(v, c.tid, wtab);
+    }
+}
+
+// ---- phase source (spec shared with oracle/rocoder_oracle.c: rco_phase_*) -----------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct PhaseKey {
+    uint32_t k0, mul;
+};
+__device__ __forceinline__ PhaseKey make_phase_key(uint64_t seed_mixed, uint32_t ch, int64_t hop) {
+    const uint64_t ctr = ((uint64_t)ch << 40) | ((uint64_t)hop & 0xFFFFFFFFFFull);
+    const uint64_t key = mix64(seed_mixed ^ ctr);
+    PhaseKey k;
+    k.k0 = (uint32_t)key;
+    k.mul = (uint32_t)(key >> 32) | 1u;
+    return k;
+}
+// returns (-cos theta, -sin theta), theta = pi * (h >> 9) * 2^-23:
+// v_cos/v_sin take revolutions; f = 0.5 + (h>>9) 2^-24 in [0.5, 1) => 2 pi f = pi + theta.
+__device__ __forceinline__ void phase_ncs(PhaseKey k, uint32_t bin, float &nc, float &ns) {
+    uint32_t x = bin * k.mul + k.k0;
+    x ^= x >> 16;
+    x *= 0x21F0AAADu;
+    x ^= x >> 15;
+    x *= 0x735A2D97u;
+    x ^= x >> 15;
+    const float f = __uint_as_float(0x3F000000u | (x >> 9));
+    nc = __builtin_amdgcn_cosf(f);
+    ns = __builtin_amdgcn_sinf(f);
+}
+
+// ---- one (ja, M - ja) bin pair -----------------------------------------------------------
+// analysis: A = Zf[ja], Bp = Zf[M-ja], w = exp(-2 pi i ja / N)
+//   X1 = 2 X[ja], X2c = 2 conj(X[M-ja])
+__device__ __forceinline__ void pair_analyze(float2 A, float2 Bp, float2 w, float2 &X1,
+                                             float2 &X2c) {
+    const float ex = A.x + Bp.x, ey = A.y - Bp.y;  // 2E = A + conj(Bp)
+    const float dx = A.x - Bp.x, dy = A.y + Bp.y;  // 2D = A - conj(Bp)
+    const float tx = dx * w.x - dy * w.y, ty = dx * w.y + dy * w.x;  // T = w D
+    X1 = make_float2(ex + ty, ey - tx);   // E - iT
+    X2c = make_float2(ex - ty, ey + tx);  // E + iT
+}
+// synthesis: magnitudes of bins ja, N-ja, M-ja, M+ja -> V[ja], V[M-ja] of the N/2-point c2r
+//   Zs[j] = (|X[j]| e^{i th_j} + |X[N-j]| e^{-i th_{N-j}}) / 2 ; nkappa = -(scale) because the
+//   phasors come negated.
+template <int LOG2N>
+__device__ __forceinline__ void pair_synth(float m1a, float m1b, float m2a, float m2b, float2 w,
+                                           uint32_t ja, PhaseKey key, float nkappa, float2 &VA,
+                                           float2 &VB) {
+    constexpr uint32_t N = 1u << LOG2N, M = N / 2;
+    float c1, s1, c2, s2, c3, s3, c4, s4;
+    phase_ncs(key, ja, c1, s1);
+    phase_ncs(key, (N - ja) & (N - 1), c2, s2);
+    phase_ncs(key, M - ja, c3, s3);
+    phase_ncs(key, M + ja, c4, s4);
+    m1a *= nkappa;
+    m1b *= nkappa;
+    m2a *= nkappa;
+    m2b *= nkappa;
+    const float px = m1a * c1 + m1b * c2, py = m1a * s1 - m1b * s2;  // Zs[ja]
+    const float qx = m2a * c3 + m2b * c4, qy = m2b * s4 - m2a * s3;  // conj(Zs[M-ja])
+    const float sx = px + qx, sy = py + qy;
+    const float rx = px - qx, ry = py - qy;
+    const float ux = rx * w.x + ry * w.y, uy = ry * w.x - rx * w.y;  // U = conj(w) R
+    VA = make_float2(sx - uy, sy + ux);  // S + iU
+    VB = make_float2(sx + uy, ux - sy);  // conj(S - iU)
+}
+
+__device__ __forceinline__ float cabs_fast(float2 z) {
+    return __builtin_amdgcn_sqrtf(z.x * z.x + z.y * z.y);
+}
+
+// pA / pB: padded LDS indices of bins ja and M - ja
+template <int LOG2N, int MODE>
+__device__ __forceinline__ void do_pair(float2 *lds, int pA, int pB, float2 w, uint32_t ja,
+                                        PhaseKey key, float2 *__restrict__ spec) {
+    constexpr uint32_t N = 1u << LOG2N, M = N / 2;
+    float2 VA, VB;
+    if constexpr (MODE == MODE_RESYNTH) {
+        const float m1a = cabs_fast(spec[ja]);
+        const float m1b = cabs_fast(spec[(N - ja) & (N - 1)]);
+        const float m2a = cabs_fast(spec[M - ja]);
+        const float m2b = cabs_fast(spec[(M + ja) & (N - 1)]);
+        pair_synth<LOG2N>(m1a, m1b, m2a, m2b, w, ja, key, -0.5f / (float)N, VA, VB);
+        lds[pA] = VA;
+        if (pB != pA) lds[pB] = VB;
+    } else {
+        const float2 A = lds[pA];
+        const float2 Bp = lds[pB];
+        float2 X1, X2c;
+        pair_analyze(A, Bp, w, X1, X2c);
+        if constexpr (MODE == MODE_FORWARD) {
+            const float2 x1 = make_float2(0.5f * X1.x, 0.5f * X1.y);
+            const float2 x2 = make_float2(0.5f * X2c.x, 0.5f * X2c.y);
+            spec[ja] = x1;                                                     // X[ja]
+            spec[(N - ja) & (N - 1)] = make_float2(x1.x, ja ? -x1.y : x1.y);   // X[N-ja]
+            spec[M - ja] = make_float2(x2.x, -x2.y);                           // X[M-ja]
+            spec[(M + ja) & (N - 1)] = ja ? x2 : make_float2(x2.x, -x2.y);     // X[M+ja]
+        } else {
+            const float m1 = cabs_fast(X1), m2 = cabs_fast(X2c);
+            pair_synth<LOG2N>(m1, m1, m2, m2, w, ja, key, -0.25f / (float)N, VA, VB);
+            lds[pA] = VA;
+            if (pB != pA) lds[pB] = VB;
+        }
+    }
+}
+
+// Middle stage on the bit-reversed spectrum in LDS (position p holds bin brev_m(p)).
+template <int LOG2N, int MODE>
+__device__ __forceinline__ void middle_stage(float2 *lds, int tid, PhaseKey key,
+                                             const float2 *__restrict__ rtab,
+                                             float2 *__restrict__ spec) {
+    using G = Geo<LOG2N>;
+    constexpr int m = G::m, M = G::M;
+    opaque(tid);  // slot addresses / twiddles are recomputed per hop instead of living in VGPRs
+#pragma unroll
+    for (int s = 0; s < G::QN; ++s) {
+        const int c = tid + G::T * s;
+        if (c == 0) continue;  // slot 0 is the special block below
+        const int j = (int)(__brev((unsigned)(2 * c)) >> (32 - (m - 1)));  // bin in (0, M/4)
+        const int j2 = M / 2 - j;
+        const int p1 = 4 * c;                                              // brev_m(j)
+        const int p2 = (int)(__brev((unsigned)j2) >> (32 - m));            // brev_m(M/2 - j)
+        const float2 w = rtab[j];
+        // pair (j, M-j): positions p1, p2+1 ; pair (M/2-j, M/2+j): positions p2, p1+1
+        do_pair<LOG2N, MODE>(lds, pad_idx(p1), pad_idx(p2 + 1), w, (uint32_t)j, key, spec);
+        do_pair<LOG2N, MODE>(lds, pad_idx(p2), pad_idx(p1 + 1), make_float2(-w.y, -w.x),
+                             (uint32_t)j2, key, spec);
+    }
+    if (tid == 0) {
+        // bins 0 (+Nyquist) at position 0, M/2 at position 1, pair (M/4, 3M/4) at 2, 3
+        do_pair<LOG2N, MODE>(lds, 0, 0, make_float2(1.f, 0.f), 0u, key, spec);
+        do_pair<LOG2N, MODE>(lds, 1, 1, make_float2(0.f, -1.f), (uint32_t)(M / 2), key, spec);
+        do_pair<LOG2N, MODE>(lds, 2, 3, rtab[M / 4], (uint32_t)(M / 4), key, spec);
+    }
+}
+
+// a_k[n] = x[k*step + n] * w[n] for this thread's 2P samples (n = tid + T q -> samples 2n, 2n+1).
+// Hops whose window runs past the end of the closed input (zero padding, stretcher.rs:129-132)
+// read from the engine's zero-padded tail copy instead, so there is no per-element bounds test.
+// Addresses are (uniform pointer + 2 T q) + 32-bit lane offset: SGPR base + VGPR offset loads,
+// no per-register 64-bit address VGPRs.
+template <int LOG2N>
+__device__ __forceinline__ void load_hop(float2 (&v)[Geo<LOG2N>::P], const HopParams &p,
+                                         const float *__restrict__ xc,
+                                         const float *__restrict__ xt,
+                                         const float *__restrict__ win, int64_t k, unsigned lane2) {
+    using G = Geo<LOG2N>;
+    const float *__restrict__ src = (k >= p.tail_hop_first)
+                                        ? xt + (k * (int64_t)p.step - p.tail_origin)
+                                        : xc + (k * (int64_t)p.step - p.in_origin);
+    // chunks of CH registers: bounds the loads in flight (input + window) to 4 CH VGPRs
+    constexpr int CH = G::P < 8 ? G::P : 8;
+#pragma unroll
+    for (int q0 = 0; q0 < G::P; q0 += CH) {
+#pragma unroll
+        for (int q = q0; q < q0 + CH; ++q) {
+            const float *__restrict__ sq = src + 2 * G::T * q;
+            const float *__restrict__ wq = win + 2 * G::T * q;
+            v[q] = make_float2(sq[lane2] * wq[lane2], sq[lane2 + 1] * wq[lane2 + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// a per-hop opaque copy of a table pointer: keeps the compiler from hoisting 2P table loads
+// out of the hop loop (they are L1/L2 hits; 64+ live VGPRs would halve occupancy)
+template <class Tp>
+__device__ __forceinline__ const Tp *per_hop(const Tp *ptr) {
+    asm volatile("" : "+s"(ptr));
+    return ptr;
+}
+
+template <int LOG2N, int MODE, bool PITCH1>
+__global__ __launch_bounds__(Geo<LOG2N>::T, 2) void hop_kernel(const HopParams p) {
+    using G = Geo<LOG2N>;
+    constexpr int P = G::P, T = G::T, M = G::M, N = G::N, H = M;
+    constexpr int LL = last_lor<G>(G::m);
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    ThreadCtx<G> ctx;
+    ctx.tid = threadIdx.x;
+    fill_lds_bases<G, G::m>(ctx);
+    const int tid = ctx.tid;
+    const uint32_t run = blockIdx.x % p.runs_per_channel;
+    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
+    int64_t k_end = k_begin + p.run_len;
+    if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
+    if (k_begin >= k_end) return;
+    const float *__restrict__ xc = p.x + (size_t)ch * p.in_stride;
+    const float *__restrict__ xt = p.xtail + (size_t)ch * p.tail_stride;
+    const unsigned lane2 = 2u * (unsigned)tid;
+    const float2 *__restrict__ wtab = p.wtab;
+    const float2 *__restrict__ rtab = p.rtab;
+
+    float2 v[P];
+    if constexpr (MODE == MODE_FORWARD) {
+        for (int64_t k = k_begin; k < k_end; ++k) {
+            float2 *spec = p.spec + ((size_t)ch * p.hop_count + (size_t)(k - p.hop_first)) * N;
+            load_hop<LOG2N>(v, p, xc, xt, per_hop(p.window), k, lane2);
+            forward_passes<G, G::m, 0, true>(v, lds, ctx, wtab);
+            lds_store<G, LL>(v, lds, ctx.lb[LL]);
+            __syncthreads();
+            middle_stage<LOG2N, MODE_FORWARD>(lds, tid, PhaseKey{0u, 1u}, rtab, spec);
+            __syncthreads();
+        }
+    } else if constexpr (MODE == MODE_RESYNTH) {
+        for (int64_t k = k_begin; k < k_end; ++k) {
+            const size_t hop_idx = (size_t)ch * p.hop_count + (size_t)(k - p.hop_first);
+            float2 *spec = p.spec + hop_idx * N;
+            const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+            middle_stage<LOG2N, MODE_RESYNTH>(lds, tid, key, rtab, spec);
+            __syncthreads();
+            lds_load<G, LL>(v, lds, ctx.lb[LL]);
+            __syncthreads();
+            inverse_passes<G, G::m>(v, lds, ctx, wtab);
+            float *y = p.ybuf + hop_idx * N;
+            const float *__restrict__ wsrc = per_hop(p.window);
+            constexpr int CH = P < 8 ? P : 8;
+#pragma unroll
+            for (int q0 = 0; q0 < P; q0 += CH) {
+#pragma unroll
+                for (int q = q0; q < q0 + CH; ++q)
+                    *reinterpret_cast<float2 *>(y + 2 * T * q + lane2) =
+                        make_float2(v[q].x * (wsrc + 2 * T * q)[lane2],
+                                    v[q].y * (wsrc + 2 * T * q)[lane2 + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        // fused path: overlap-add in registers. head slot q' <-> tail slot q' + P/2.
+        constexpr int PH = P / 2;
+        float2 tail[PH];
+#pragma unroll
+        for (int q = 0; q < PH; ++q) tail[q] = make_float2(0.f, 0.f);
+        float *__restrict__ outc = p.out + (size_t)ch * p.out_stride;
+        const uint32_t pitch = PITCH1 ? 1u : p.pitch;
+        // hop k_begin - 1 is recomputed only for its tail (global hop 0 has a zero predecessor:
+        // src/stretcher.rs:58-59)
+        for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
+            const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+            load_hop<LOG2N>(v, p, xc, xt, per_hop(p.window), k, lane2);
+            forward_passes<G, G::m, 0, true>(v, lds, ctx, wtab);
+            lds_store<G, LL>(v, lds, ctx.lb[LL]);
+            __syncthreads();
+            middle_stage<LOG2N, MODE_FUSED>(lds, tid, key, rtab, nullptr);
+            __syncthreads();
+            lds_load<G, LL>(v, lds, ctx.lb[LL]);
+            __syncthreads();
+            inverse_passes<G, G::m>(v, lds, ctx, wtab);
+            {
+                const float *__restrict__ wsrc = per_hop(p.window);
+                constexpr int CH = P < 8 ? P : 8;
+#pragma unroll
+                for (int q0 = 0; q0 < P; q0 += CH) {
+#pragma unroll
+                    for (int q = q0; q < q0 + CH; ++q)
+                        v[q] = make_float2(v[q].x * (wsrc + 2 * T * q)[lane2],
+                                           v[q].y * (wsrc + 2 * T * q)[lane2 + 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (k >= k_begin) {
+                const int64_t g0 = k * (int64_t)H;  // absolute O index of this hop's first sample
+                const float *__restrict__ esrc = per_hop(p.env);
+                if constexpr (PITCH1) {
+                    float *dst = outc + (g0 - p.out_origin);
+                    constexpr int CH = PH < 8 ? PH : 8;
+#pragma unroll
+                    for (int q0 = 0; q0 < PH; q0 += CH) {
+#pragma unroll
+                        for (int q = q0; q < q0 + CH; ++q) {
+                            float2 o;  // stretcher.rs:97-100 operation order
+                            o.x = (v[q].x + tail[q].x) * (esrc + 2 * T * q)[lane2] * p.amp;
+                            o.y = (v[q].y + tail[q].y) * (esrc + 2 * T * q)[lane2 + 1] * p.amp;
+                            *reinterpret_cast<float2 *>(dst + 2 * T * q + lane2) = o;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    // F[t] = O[t p]: keep element g = g0 + i iff g % p == 0, at F[g / p]
+                    const int64_t kq = g0 / pitch;
+                    const uint32_t kr = (uint32_t)(g0 % pitch);
+                    float *dst = outc + (kq - p.out_origin);
+                    int t2 = tid;
+                    opaque(t2);
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) {
+                        const uint32_t i0 = 2u * (uint32_t)(t2 + T * q);
+                        const float o0 = (v[q].x + tail[q].x) * (esrc + 2 * T * q)[lane2] * p.amp;
+                        const float o1 = (v[q].y + tail[q].y) * (esrc + 2 * T * q)[lane2 + 1] * p.amp;
+                        const uint32_t a0 = kr + i0, a1 = a0 + 1;
+                        const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
+                        if (d0 * pitch == a0) dst[d0] = o0;
+                        if (d1 * pitch == a1) dst[d1] = o1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PH; ++q) tail[q] = v[q + PH];
+        }
+    }
+}
+
+// Overlap-add for the user-kernel path (gather form, two terms per output sample).
+__global__ __launch_bounds__(256) void ola_kernel(const OlaParams p) {
+    const uint32_t N = 1u << p.log2n, H = N / 2;
+    const int64_t hop_local = blockIdx.x;
+    const uint32_t ch = blockIdx.y;
+    const int64_t k = p.hop_first + hop_local;
+    const float *yk = p.ybuf + ((size_t)ch * p.hop_count + (size_t)hop_local) * N;
+    const float *prev = hop_local > 0 ? yk - N + H : p.tail + (size_t)ch * H;
+    float *outc = p.out + (size_t)ch * p.out_stride;
+    const int64_t g0 = k * (int64_t)H;
+    for (uint32_t i = threadIdx.x; i < H; i += blockDim.x) {
+        const int64_t g = g0 + i;
+        if (p.pitch == 1 || g % p.pitch == 0) {
+            const float o = (yk[i] + prev[i]) * p.env[i] * p.amp;
+            outc[g / p.pitch - p.out_origin] = o;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void ola_save_tail_kernel(const OlaParams p) {
+    const uint32_t N = 1u << p.log2n, H = N / 2;
+    const uint32_t ch = blockIdx.y;
+    const float *yl = p.ybuf + ((size_t)ch * p.hop_count + (size_t)(p.hop_count - 1)) * N + H;
+    float *t = p.tail + (size_t)ch * H;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < H; i += gridDim.x * blockDim.x)
+        t[i] = yl[i];
+}
+
+template <int LOG2N>
+hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
+    using G = Geo<LOG2N>;
+    const dim3 grid(p.runs_per_channel * p.n_channels), block(G::T);
+    const size_t lds = sizeof(float2) * G::LDS_FLOAT2;
+    switch (mode) {
+        case MODE_FUSED:
+            if (p.pitch == 1)
+                hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true>), grid, block, lds, s, p);
+            else
+                hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, false>), grid, block, lds, s, p);
+            break;
+        case MODE_FORWARD:
+            hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FORWARD, true>), grid, block, lds, s, p);
+            break;
+        case MODE_RESYNTH:
+            hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_RESYNTH, true>), grid, block, lds, s, p);
+            break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool hop_geometry(int log2n, int *threads, size_t *lds_bytes) {
+    if (log2n < 5 || log2n > 14) return false;
+    const int m = log2n - 1, M = 1 << m;
+    const int T = cmax(M / 32, cmin(64, M / 4));
+    if (threads) *threads = T;
+    if (lds_bytes) *lds_bytes = sizeof(float2) * (size_t)(M + (M >> 5) + 1);
+    return true;
+}
+
+hipError_t launch_hop(int log2n, HopMode mode, const HopParams &p, hipStream_t s) {
+    switch (log2n) {
+        case 5: return launch_hop_n<5>(mode, p, s);
+        case 6: return launch_hop_n<6>(mode, p, s);
+        case 7: return launch_hop_n<7>(mode, p, s);
+        case 8: return launch_hop_n<8>(mode, p, s);
+        case 9: return launch_hop_n<9>(mode, p, s);
+        case 10: return launch_hop_n<10>(mode, p, s);
+        case 11: return launch_hop_n<11>(mode, p, s);
+        case 12: return launch_hop_n<12>(mode, p, s);
+        case 13: return launch_hop_n<13>(mode, p, s);
+        case 14: return launch_hop_n<14>(mode, p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_ola(const OlaParams &p, hipStream_t s) {
+    const dim3 grid((unsigned)p.hop_count, p.n_channels), block(256);
+    hipLaunchKernelGGL(ola_kernel, grid, block, 0, s, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const dim3 g2(4, p.n_channels);
+    hipLaunchKernelGGL(ola_save_tail_kernel, g2, block, 0, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace rc

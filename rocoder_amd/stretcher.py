@@ -1,0 +1,411 @@
+"""Host-side mirror of the reference's interface for the hot path, above the C-ABI.
+
+Names, argument meaning and error behaviour follow the reference (file:line = rocoder v0.4.0):
+  * `Stretcher`          — src/stretcher.rs:12-136 (`new`, `next_window`, `is_done`, `channel_bound`)
+  * `ReFFT`              — src/fft.rs:15-109 (`forward_fft`, `resynth`)
+  * `StretcherProcessor` — src/stretcher_processor.rs:21-89 (one thread, round-robin channels,
+                           bounded queues, Shutdown control message)
+  * `AudioSpec`/`AudioBus` — src/audio.rs:31-37,141-224
+All numerics run in the HIP engine (librocoder_hip.so); nothing here computes audio on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import queue
+import threading
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import RC_WOULD_BLOCK, RocoderError, check, rc_config, rc_params
+
+
+@dataclass(frozen=True)
+class AudioSpec:  # src/audio.rs:31-37
+    channels: int = 2
+    sample_rate: int = 44100
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _wrap_kernel(pyfunc):
+    """Python callable (time_ms, complex64[N]) -> complex64[N] as the C-ABI rc_freq_kernel.
+    Raising (or returning the wrong length) is the equivalent of a panic (src/fft.rs:100-106)."""
+    if pyfunc is None:
+        return C.cast(None, _lib.FREQ_KERNEL)
+    if isinstance(pyfunc, _lib.FREQ_KERNEL):
+        return pyfunc
+
+    def tramp(time_ms, pin, pout, n, _user):
+        try:
+            a = np.ctypeslib.as_array(pin, shape=(2 * n,)).view(np.complex64)
+            r = np.asarray(pyfunc(int(time_ms), a.copy()), dtype=np.complex64)
+            if r.size != n:
+                return 2
+            np.ctypeslib.as_array(pout, shape=(2 * n,))[:] = r.view(np.float32)
+            return 0
+        except Exception:  # noqa: BLE001 - a panicking kernel must not poison the batch
+            return 1
+
+    return _lib.FREQ_KERNEL(tramp)
+
+
+def load_kernel_library(path: str):
+    """dlopen a shared object exporting the C symbol `apply` with the rc_freq_kernel signature
+    (the C-ABI form of README.md:106-112; src/fft.rs:93-94 resolves the same name)."""
+    so = C.CDLL(path)
+    fn = so.apply
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_uint64, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t, C.c_void_p]
+    k = C.cast(fn, _lib.FREQ_KERNEL)
+    k._keepalive = so  # keep the library loaded, like the kernel stack at src/fft.rs:21
+    return k
+
+
+def make_config(window_len=16384, factor=1.0, amplitude=1.0, pitch_multiple=1, sample_rate=44100,
+                channels=1, buffer_secs=1.0, seed=0, device=0, window=None, kernel=None,
+                kernel_time_ms=0, max_batch_hops=0):
+    cfg = rc_config()
+    cfg.struct_size = C.sizeof(rc_config)
+    cfg.window_len = int(window_len)
+    cfg.factor = float(factor)
+    cfg.amplitude = float(amplitude)
+    cfg.pitch_multiple = int(pitch_multiple)
+    cfg.sample_rate = int(sample_rate)
+    cfg.channels = int(channels)
+    cfg.buffer_secs = float(buffer_secs)
+    cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    cfg.device = int(device)
+    cfg.max_batch_hops = int(max_batch_hops)
+    keep = []
+    if window is not None:
+        w = np.ascontiguousarray(window, dtype=np.float32)
+        if w.size != window_len:
+            raise ValueError("window length mismatch")
+        cfg.window = _fp(w)
+        keep.append(w)
+    k = _wrap_kernel(kernel)
+    cfg.kernel = k
+    keep.append(k)
+    cfg.kernel_time_ms = int(kernel_time_ms)
+    return cfg, keep
+
+
+def derive_params(**kw) -> rc_params:
+    """Stretcher::new parameter derivation (src/stretcher.rs:40-56) — host only, no device."""
+    cfg, _keep = make_config(**kw)
+    out = rc_params()
+    check(_lib.lib().rc_derive_params(C.byref(cfg), C.byref(out)))
+    return out
+
+
+def offline_output_len(in_len: int, **kw) -> int:
+    cfg, _keep = make_config(**kw)
+    return int(_lib.lib().rc_offline_output_len(C.byref(cfg), in_len))
+
+
+class Engine:
+    """Thin RAII wrapper of rc_engine (all channels of one job)."""
+
+    def __init__(self, **kw):
+        self._L = _lib.lib()
+        self._cfg, self._keep = make_config(**kw)
+        h = C.c_void_p()
+        check(self._L.rc_engine_create(C.byref(self._cfg), C.byref(h)))
+        self._h = h
+        self.params = rc_params()
+        check(self._L.rc_engine_get_params(self._h, C.byref(self.params)))
+        self.channels = int(self._cfg.channels)
+        self.window_len = int(self._cfg.window_len)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rc_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- streaming seam
+    def push_input(self, channel: int, samples):
+        s = np.ascontiguousarray(samples, dtype=np.float32)
+        check(self._L.rc_engine_push_input(self._h, channel, _fp(s), s.size))
+
+    def close_input(self, channel: int):
+        check(self._L.rc_engine_close_input(self._h, channel))
+
+    def next_window(self, channel: int) -> Optional[np.ndarray]:
+        """One Stretcher::next_window; None when the reference would block on recv()."""
+        out = np.empty(self.params.window_out_len, np.float32)
+        n = C.c_size_t(0)
+        rc = check(self._L.rc_engine_next_window(self._h, channel, _fp(out), out.size, C.byref(n)))
+        if rc == RC_WOULD_BLOCK:
+            return None
+        return out[: n.value]
+
+    def is_done(self, channel: int) -> bool:
+        return bool(check(self._L.rc_engine_is_done(self._h, channel)))
+
+    def channel_bound(self) -> int:
+        return int(self._L.rc_engine_channel_bound(self._h))
+
+    # ---- offline
+    def output_len(self, in_len: int) -> int:
+        return int(self._L.rc_offline_output_len(C.byref(self._cfg), in_len))
+
+    def stretch_host(self, channels_in) -> np.ndarray:
+        x = np.ascontiguousarray(np.atleast_2d(channels_in), dtype=np.float32)
+        if x.shape[0] != self.channels:
+            raise ValueError("channel count mismatch")
+        n_out = self.output_len(x.shape[1])
+        out = np.empty((self.channels, n_out), np.float32)
+        fp = C.POINTER(C.c_float)
+        ins = (fp * self.channels)(*[_fp(x[c]) for c in range(self.channels)])
+        outs = (fp * self.channels)(*[_fp(out[c]) for c in range(self.channels)])
+        got = C.c_size_t(0)
+        check(self._L.rc_engine_stretch_host(self._h, ins, x.shape[1], outs, n_out, C.byref(got)))
+        assert got.value == n_out
+        return out
+
+    def stretch_device_ptr(self, d_in: int, in_stride: int, in_len: int, d_out: int, out_stride: int,
+                           out_cap: int, stream: int = 0) -> int:
+        got = C.c_size_t(0)
+        check(self._L.rc_engine_stretch_device(self._h, C.c_void_p(d_in), in_stride, in_len,
+                                               C.c_void_p(d_out), out_stride, out_cap, C.byref(got),
+                                               C.c_void_p(stream)))
+        return got.value
+
+    def stretch_device_range_ptr(self, d_in: int, in_stride: int, in_len: int, ch_first: int,
+                                 ch_count: int, win_first: int, win_count: int, d_out: int,
+                                 out_stride: int, out_cap: int, stream: int = 0):
+        check(self._L.rc_engine_stretch_device_range(self._h, C.c_void_p(d_in), in_stride, in_len,
+                                                     ch_first, ch_count, win_first, win_count,
+                                                     C.c_void_p(d_out), out_stride, out_cap,
+                                                     C.c_void_p(stream)))
+
+    def stretch_tensor(self, x, out=None, stream=None):
+        """x: torch float32 CUDA tensor [channels, L] (device-resident). Returns [channels, n_out]."""
+        import torch
+
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        n_out = self.output_len(x.shape[1])
+        if out is None:
+            out = torch.empty((self.channels, n_out), dtype=torch.float32, device=x.device)
+        s = torch.cuda.current_stream(x.device).cuda_stream if stream is None else stream
+        self.stretch_device_ptr(x.data_ptr(), x.stride(0), x.shape[1], out.data_ptr(), out.stride(0),
+                                out.shape[1], s)
+        return out
+
+    def last_kernel_stats(self):
+        ms, hops, launches = C.c_float(0), C.c_uint64(0), C.c_uint32(0)
+        check(self._L.rc_engine_last_kernel_stats(self._h, C.byref(ms), C.byref(hops),
+                                                  C.byref(launches)))
+        return float(ms.value), int(hops.value), int(launches.value)
+
+    # ---- single hop (ReFFT seam)
+    def forward_fft(self, samples) -> np.ndarray:
+        s = np.ascontiguousarray(samples, dtype=np.float32)
+        assert s.size == self.window_len
+        out = np.empty(2 * self.window_len, np.float32)
+        check(self._L.rc_engine_forward_fft(self._h, _fp(s), _fp(out)))
+        return out.view(np.complex64)
+
+    def resynth(self, channel: int, hop: int, samples) -> np.ndarray:
+        s = np.ascontiguousarray(samples, dtype=np.float32)
+        assert s.size == self.window_len
+        out = np.empty(self.window_len, np.float32)
+        check(self._L.rc_engine_resynth(self._h, channel, hop, _fp(s), _fp(out)))
+        return out
+
+
+class ReFFT:
+    """src/fft.rs ReFFT: `new(window, kernel_src)`, `forward_fft`, `resynth`. The unseedable
+    thread_rng of src/fft.rs:64 is replaced by the (seed, channel, hop) phase key."""
+
+    def __init__(self, window, kernel=None, seed=0, channel_index=0, device=0, kernel_time_ms=0):
+        w = np.ascontiguousarray(window, dtype=np.float32)
+        self.window_len = w.size
+        self.channel_index = channel_index
+        self.hop = 0
+        self._e = Engine(window_len=w.size, window=w, channels=channel_index + 1, seed=seed,
+                         device=device, kernel=kernel, kernel_time_ms=kernel_time_ms)
+
+    def forward_fft(self, samples) -> np.ndarray:  # src/fft.rs:50-61
+        return self._e.forward_fft(samples)
+
+    def resynth(self, samples, hop: Optional[int] = None) -> np.ndarray:  # src/fft.rs:42-48
+        k = self.hop if hop is None else hop
+        out = self._e.resynth(self.channel_index, k, samples)
+        if hop is None:
+            self.hop += 1
+        return out
+
+
+class Stretcher:
+    """src/stretcher.rs Stretcher — one channel. `input` is the Receiver<Vec<f32>> side: a
+    `queue.Queue` carrying float arrays, `None` meaning the Sender was dropped."""
+
+    def __init__(self, spec: AudioSpec, input: "queue.Queue", factor: float, amplitude: float,  # noqa: A002
+                 pitch_multiple: int, window, buffer_dur: float = 1.0, frequency_kernel=None,
+                 seed: int = 0, channel_index: int = 0, device: int = 0, _engine: Engine = None,
+                 kernel_time_ms: int = 0):
+        self.spec = spec
+        self.input = input
+        self.channel_index = channel_index
+        w = np.ascontiguousarray(window, dtype=np.float32)
+        self._e = _engine or Engine(
+            window_len=w.size, window=w, factor=factor, amplitude=amplitude,
+            pitch_multiple=pitch_multiple, sample_rate=spec.sample_rate,
+            channels=max(spec.channels, channel_index + 1), buffer_secs=buffer_dur, seed=seed,
+            device=device, kernel=frequency_kernel, kernel_time_ms=kernel_time_ms)
+        self.window_len = w.size
+        self._closed = False
+
+    def is_done(self) -> bool:  # src/stretcher.rs:78-80
+        return self._e.is_done(self.channel_index)
+
+    def channel_bound(self) -> int:  # src/stretcher.rs:82-85
+        return self._e.channel_bound()
+
+    def _pump(self, block: bool) -> bool:
+        """Move chunks from the input queue into the engine; True if anything arrived."""
+        got = False
+        while not self._closed:
+            try:
+                chunk = self.input.get(block=block and not got)
+            except queue.Empty:
+                break
+            got = True
+            if chunk is None:
+                self._e.close_input(self.channel_index)
+                self._closed = True
+            else:
+                self._e.push_input(self.channel_index, chunk)
+        return got
+
+    def next_window(self) -> np.ndarray:  # src/stretcher.rs:87-121
+        self._pump(block=False)
+        while True:
+            w = self._e.next_window(self.channel_index)
+            if w is not None:
+                return w
+            # the reference blocks in self.input.recv() (src/stretcher.rs:125)
+            self._pump(block=True)
+
+
+class AudioBus:  # src/audio.rs:141-224
+    def __init__(self, spec: AudioSpec, channels: List["queue.Queue"],
+                 expected_total_samples: Optional[int]):
+        self.spec = spec
+        self.channels = channels
+        self.expected_total_samples = expected_total_samples
+
+    def into_audio(self, timeout: float = 0.005) -> List[np.ndarray]:  # src/audio.rs:152-172
+        out: List[List[np.ndarray]] = [[] for _ in self.channels]
+        closed = [False] * len(self.channels)
+        while not all(closed):
+            for i, ch in enumerate(self.channels):
+                if closed[i]:
+                    continue
+                try:
+                    chunk = ch.get(timeout=timeout)
+                except queue.Empty:
+                    continue
+                if chunk is None:
+                    closed[i] = True
+                else:
+                    out[i].append(chunk)
+        return [np.concatenate(c) if c else np.zeros(0, np.float32) for c in out]
+
+
+class StretcherProcessor:
+    """src/stretcher_processor.rs: ONE thread, `loop { ctrl; for ch { if done break 'outer;
+    send(next_window()) } }`, bounded(channel_bound()) output queues (back-pressure)."""
+
+    SHUTDOWN = "Shutdown"  # StretcherProcessorControlMessage::Shutdown (:11-19)
+
+    def __init__(self, channel_stretchers: Sequence[Stretcher],
+                 expected_total_samples: Optional[int] = None):
+        self.spec = channel_stretchers[0].spec
+        self._channels = []
+        receivers = []
+        for s in channel_stretchers:  # :33-37
+            q: "queue.Queue" = queue.Queue(maxsize=max(1, s.channel_bound()))
+            self._channels.append((q, s))
+            receivers.append(q)
+        self.bus = AudioBus(self.spec, receivers, expected_total_samples)
+        self._ctrl: "queue.Queue" = queue.Queue()
+        self._finished = threading.Event()
+        self._thread: Optional[threading.Thread] = None
+        self.error: Optional[BaseException] = None
+
+    @classmethod
+    def new(cls, channel_stretchers, expected_total_samples=None):  # :26-46
+        p = cls(channel_stretchers, expected_total_samples)
+        return p, p.bus
+
+    def _handle_control_messages(self) -> bool:  # :77-88 (non-blocking try_recv)
+        try:
+            msg = self._ctrl.get_nowait()
+        except queue.Empty:
+            return False
+        return msg == self.SHUTDOWN
+
+    def _run(self):
+        try:
+            running = True
+            while running:  # :56-71
+                if self._handle_control_messages():
+                    break
+                for out, stretcher in self._channels:
+                    if stretcher.is_done():  # :64-68 "assuming each stretcher finishes at the same time"
+                        running = False
+                        break
+                    out.put(stretcher.next_window())  # :69 blocks when the bounded queue is full
+        except BaseException as e:  # noqa: BLE001
+            self.error = e
+        finally:
+            for out, _ in self._channels:  # Senders dropped when the thread ends
+                out.put(None)
+            self._finished.set()  # :72
+
+    def start(self):  # :50-75
+        self._thread = threading.Thread(target=self._run, name="stretcher-processor", daemon=True)
+        self._thread.start()
+        return self
+
+    def shutdown(self):  # Node::shutdown, src/signal_flow/node.rs:45-48
+        self._ctrl.put(self.SHUTDOWN)
+
+    def join(self, timeout=None):  # Node::join, src/signal_flow/node.rs:50-52
+        if self._thread:
+            self._thread.join(timeout)
+        if self.error:
+            raise self.error
+
+    def is_finished(self) -> bool:  # src/signal_flow/node.rs:54-56
+        return self._finished.is_set()
+
+
+def stretch(channels_in, window_len=16384, factor=1.0, amplitude=1.0, pitch_multiple=1, seed=0,
+            sample_rate=44100, kernel=None, device=0, kernel_time_ms=0) -> np.ndarray:
+    """Offline `-o` run (src/main.rs:124-160 minus file I/O): host [C, L] -> host [C, n_out]."""
+    x = np.ascontiguousarray(np.atleast_2d(channels_in), dtype=np.float32)
+    with Engine(window_len=window_len, factor=factor, amplitude=amplitude,
+                pitch_multiple=pitch_multiple, sample_rate=sample_rate, channels=x.shape[0],
+                seed=seed, device=device, kernel=kernel, kernel_time_ms=kernel_time_ms) as e:
+        return e.stretch_host(x)
+
+
+__all__ = ["AudioSpec", "AudioBus", "Engine", "ReFFT", "Stretcher", "StretcherProcessor", "stretch",
+           "derive_params", "offline_output_len", "load_kernel_library", "RocoderError"]

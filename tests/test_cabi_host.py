@@ -1,0 +1,116 @@
+"""CPU tests (-m "not gpu") of the C-ABI library: it loads, exports every symbol the header
+declares, its host-only helpers agree with the oracle, and compute fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import cbind as oc
+from oracle import oracle_np as onp
+
+rocoder_amd = pytest.importorskip("rocoder_amd")
+from rocoder_amd import _lib  # noqa: E402
+from rocoder_amd.stretcher import derive_params, make_config, offline_output_len  # noqa: E402
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "rocoder_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rc_[a-z0-9_]+)\s*\(", src)) - {"rc_freq_kernel"})
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    names = _header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/rocoder_hip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
+    assert L.rc_abi_version() == 1
+
+
+@pytest.mark.parametrize("N,f,p,a", [(16384, 1.0, 1, 1.0), (16384, 8.0, 1, 1.0), (16384, 8.0, 3, 1.0),
+                                     (65536, 32.0, 1, 1.0), (1024, 2.0, 2, 0.7), (256, 0.5, 1, 1.0),
+                                     (16384, 8.0, -2, 1.0), (16384, 40.0, 5, 2.0)])
+def test_derive_params_matches_oracle(N, f, p, a):  # src/stretcher.rs:40-56
+    got = derive_params(window_len=N, factor=f, pitch_multiple=p, amplitude=a)
+    s = oc.Stretcher(factor=f, amplitude=a, pitch_multiple=p, window=np.ones(N, np.float32))
+    assert got.sample_step_len == s.step
+    assert got.samples_needed_per_window == s.samples_needed_per_window
+    assert got.corrected_amp_factor == np.float32(s.amp)
+    assert got.half_window_len == N // 2
+    assert got.hops_per_window == (2 * p if p > 0 else -(-s.samples_needed_per_window // (N - N // 2)))
+
+
+@pytest.mark.parametrize("bad", [dict(pitch_multiple=0), dict(factor=200.0, window_len=256),
+                                 dict(factor=0.25, window_len=256), dict(pitch_multiple=-1),
+                                 dict(window_len=1), dict(channels=0)])
+def test_invalid_parameters_rejected(bad):
+    with pytest.raises(_lib.RocoderError) as ei:
+        derive_params(**bad)
+    assert ei.value.code == _lib.RC_EINVAL
+
+
+@pytest.mark.parametrize("L,N,f,p", [(26460000, 16384, 8.0, 1), (26460000, 16384, 8.0, 3),
+                                     (2646000, 16384, 1.0, 1), (5292000, 65536, 32.0, 1),
+                                     (0, 256, 1.0, 1), (100, 256, 4.0, 1), (256, 256, 1.0, 1),
+                                     (3001, 256, 8.0, 3)])
+def test_offline_output_len_matches_oracle(L, N, f, p):
+    assert offline_output_len(L, window_len=N, factor=f, pitch_multiple=p) == \
+        oc.offline_output_len(L, N, f, p)
+
+
+def test_baseline_config_lengths():  # BASELINE.md §3 derived columns
+    assert offline_output_len(2646000, window_len=16384, factor=1.0) == 2637824
+    assert offline_output_len(26460000, window_len=16384, factor=8.0) == 211566592
+    assert offline_output_len(26460000, window_len=16384, factor=8.0, pitch_multiple=3) == 211763200
+    assert offline_output_len(5292000, window_len=65536, factor=32.0) == 167313408
+
+
+def test_phase_source_spec_matches_oracle(goldens):
+    z, meta = goldens
+    L = _lib.lib()
+    key = L.rc_phase_key(0x5EED, 1, 7)
+    assert key == meta["hop1024"]["key"] == oc.phase_key(0x5EED, 1, 7)
+    for b, h in zip(z["phase/bins"], z["phase/hash"]):
+        assert L.rc_phase_hash(key, int(b)) == int(h)
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        seed, ch, hop, b = (int(rng.integers(0, 2**63)), int(rng.integers(0, 65536)),
+                            int(rng.integers(0, 2**40)), int(rng.integers(0, 2**16)))
+        k = L.rc_phase_key(seed, ch, hop)
+        assert k == onp.phase_key(seed, ch, hop)
+        assert L.rc_phase_hash(k, b) == int(onp.phase_hash(k, [b])[0])
+
+
+def test_compute_fails_loudly_without_gpu():
+    L = _lib.lib()
+    if L.rc_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.RocoderError) as ei:
+        rocoder_amd.Engine(window_len=1024)
+    assert ei.value.code == _lib.RC_ENODEVICE
+    with pytest.raises(_lib.RocoderError):
+        rocoder_amd.stretch(np.zeros((1, 4096), np.float32), window_len=1024)
+
+
+def test_unsupported_window_is_reported_not_faked():
+    cfg, _k = make_config(window_len=1000)
+    h = C.c_void_p()
+    rc = _lib.lib().rc_engine_create(C.byref(cfg), C.byref(h))
+    assert rc == _lib.RC_EUNSUPPORTED and not h.value
+
+
+def test_product_path_never_touches_the_oracle():
+    """rocoder_amd/ must not import, link or execute anything under oracle/."""
+    pk = os.path.join(ROOT, "rocoder_amd")
+    for dp, _dn, fns in os.walk(pk):
+        for fn in fns:
+            if fn.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                for pat in (r"^\s*(from|import)\s+oracle", r"#include\s*[\"<][^\n]*oracle",
+                            r"librocoder_oracle", r"rco_[a-z_]+\s*\(", r"oracle[/.](cbind|oracle_np)"):
+                    assert not re.search(pat, txt, flags=re.M), (os.path.join(dp, fn), pat)

@@ -1,0 +1,93 @@
+"""CPU tests of the multi-GPU path: the shard plan and the one collective (segment gather), run
+with world_size 2/3 on the gloo backend. The per-shard compute is injected: here it is the CPU
+oracle (tests may use it as the checker); on a GPU node it is rocoder_amd.distributed.engine_compute."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from rocoder_amd.distributed import Shard, shard_plan
+
+
+@pytest.mark.parametrize("channels,windows,world", [(2, 12913, 1), (2, 12913, 2), (2, 12913, 4),
+                                                    (2, 12913, 8), (8, 2553, 8), (8, 2553, 4),
+                                                    (2, 7, 3), (1, 1, 8), (3, 10, 2), (2, 0, 4)])
+def test_shard_plan_partitions_every_window_once(channels, windows, world):
+    plan = shard_plan(channels, windows, world)
+    cover = np.zeros((channels, max(windows, 1)), np.int32)
+    for s in plan:
+        assert 0 <= s.rank < world and s.ch_count >= 1 and s.win_count >= 1
+        cover[s.ch_first:s.ch_first + s.ch_count, s.win_first:s.win_first + s.win_count] += 1
+    if windows:
+        assert np.all(cover == 1)
+    # balanced: no rank holds more than ceil(units/world) + 1 windows-worth of a fair share
+    if windows >= world and plan:
+        load = np.zeros(world)
+        for s in plan:
+            load[s.rank] += s.ch_count * s.win_count
+        assert load.max() <= np.ceil(channels * windows / world) + channels
+
+
+def test_baseline_c5_is_one_channel_per_gpu():  # 8 channels -> 1 channel/GPU, zero halo
+    plan = shard_plan(8, 2553, 8)
+    assert [(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan] == \
+        [(r, r, 1, 0, 2553) for r in range(8)]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, x, full_ref, N, f, p, wout, nwin, dst, q):
+    import torch
+    import torch.distributed as dist
+
+    from rocoder_amd.distributed import stretch_sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def compute(s: Shard):
+            # checker-side compute: the shard's slice of the oracle's full output
+            blk = full_ref[s.ch_first:s.ch_first + s.ch_count,
+                           s.win_first * wout:(s.win_first + s.win_count) * wout]
+            return torch.from_numpy(np.ascontiguousarray(blk))
+
+        out = stretch_sharded(compute, x.shape[0], nwin, wout, dst=dst)
+        if dst is None or rank == dst:
+            q.put((rank, np.array_equal(out.numpy(), full_ref)))
+        else:
+            q.put((rank, out is None))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dst", [(2, 0), (3, None)])
+def test_sharded_gather_gloo(world, dst):
+    import torch.multiprocessing as mp
+
+    from oracle import cbind as oc
+    from oracle import oracle_np as onp
+
+    N, f, p = 256, 4.0, 1
+    x = np.stack([onp.synth_input(c, 6000) for c in range(2)])
+    full = oc.stretch_offline(x, N, f, 1.0, p, seed=3)
+    wout = N
+    nwin = full.shape[1] // wout
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, x, full, N, f, p, wout, nwin, dst, q))
+             for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert all(ok for _, ok in res), res
