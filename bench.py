@@ -115,18 +115,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        eng.stretch_tensor(x, out=out)
+    # a real (non-default) stream: the engine launches its kernel on exactly this stream, and the
+    # events below are recorded on it, so they bracket the hop-kernel launches
+    stream = torch.cuda.Stream(device)
     barrier()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()  # torch's current stream == the stream the engine launches on (stretch_tensor)
-    for _ in range(args.steps):
-        eng.stretch_tensor(x, out=out)
-    ev1.record()
-    barrier()
-    dt = time.perf_counter() - t0
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            eng.stretch_tensor(x, out=out)
+        barrier()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(args.steps):
+            eng.stretch_tensor(x, out=out)
+        ev1.record(stream)
+        barrier()
+        dt = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # per launch (one hop-kernel launch per step)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)

@@ -135,6 +135,10 @@ int rc_engine_stretch_device_range(rc_engine *e, const float *d_in, size_t in_st
                                    uint64_t win_first, uint64_t win_count, float *d_out,
                                    size_t out_stride, size_t out_cap, void *hip_stream);
 
+/* Blocks until everything the engine queued on ITS OWN stream has finished (calls that were given
+ * a caller stream are ordered by that stream instead). */
+int rc_engine_synchronize(rc_engine *e);
+
 /* ---- measurement ---------------------------------------------------------------------- */
 /* HIP-event time (ms) and hop count of the hop kernel launches of the last offline call;
  * synchronises on the events. */

@@ -78,6 +78,7 @@ SYMBOLS = {
     "rc_engine_stretch_device_range": (C.c_int, [_eng, C.c_void_p, _sz, _sz, C.c_uint32, C.c_uint32,
                                                  C.c_uint64, C.c_uint64, C.c_void_p, _sz, _sz,
                                                  C.c_void_p]),
+    "rc_engine_synchronize": (C.c_int, [_eng]),
     "rc_engine_last_kernel_stats": (C.c_int, [_eng, C.POINTER(C.c_float), C.POINTER(C.c_uint64),
                                               C.POINTER(C.c_uint32)]),
     "rc_engine_forward_fft": (C.c_int, [_eng, _fp, _fp]),
@@ -102,6 +103,14 @@ def lib() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7). Two
+    # HIP runtimes in one process do not work ("No HIP GPUs are available" for the second), so if
+    # torch is installed let it load first: our DT_NEEDED libamdhip64.so.7 then resolves to the
+    # runtime that is already mapped. Without torch the system runtime under /opt/rocm is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError if the ABI lost a symbol

@@ -651,6 +651,13 @@ int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, 
     return RC_OK;
 }
 
+int rc_engine_synchronize(rc_engine *e) {
+    if (!e) return fail(RC_EINVAL, "null engine");
+    RC_HIP(hipSetDevice(e->device));
+    RC_HIP(hipStreamSynchronize(e->stream));
+    return RC_OK;
+}
+
 int rc_engine_last_kernel_stats(rc_engine *e, float *kernel_ms, uint64_t *hops, uint32_t *launches) {
     if (!e) return fail(RC_EINVAL, "null engine");
     if (!e->stats_valid) return fail(RC_EINVAL, "no timed launch recorded yet");

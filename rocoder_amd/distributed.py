@@ -109,9 +109,13 @@ def engine_compute(engine, x):
     def compute(s: Shard):
         out = torch.empty((s.ch_count, s.win_count * wout), dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream(x.device).cuda_stream
+        if stream == 0:  # see Engine.stretch_tensor
+            torch.cuda.current_stream(x.device).synchronize()
         engine.stretch_device_range_ptr(x.data_ptr(), x.stride(0), x.shape[1], s.ch_first, s.ch_count,
                                         s.win_first, s.win_count, out.data_ptr(), out.stride(0),
                                         out.shape[1], stream)
+        if stream == 0:
+            engine.synchronize()
         return out
 
     return compute

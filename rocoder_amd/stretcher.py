@@ -202,9 +202,18 @@ class Engine:
         if out is None:
             out = torch.empty((self.channels, n_out), dtype=torch.float32, device=x.device)
         s = torch.cuda.current_stream(x.device).cuda_stream if stream is None else stream
+        if s == 0:
+            # legacy default stream: handle 0 means "the engine's own stream" in the C-ABI, so
+            # order the call by hand (inputs ready before, outputs ready after)
+            torch.cuda.current_stream(x.device).synchronize()
         self.stretch_device_ptr(x.data_ptr(), x.stride(0), x.shape[1], out.data_ptr(), out.stride(0),
                                 out.shape[1], s)
+        if s == 0:
+            self.synchronize()
         return out
+
+    def synchronize(self):
+        check(self._L.rc_engine_synchronize(self._h))
 
     def last_kernel_stats(self):
         ms, hops, launches = C.c_float(0), C.c_uint64(0), C.c_uint32(0)
