@@ -52,13 +52,14 @@ def synth_on_device(torch, device, channels, length):
 
 def cpu_baseline():
     """Time the oracle (a port of the reference algorithm, 1 thread for all channels) on a bounded
-    sample: stereo, L = 3 000 000 per channel, same window/factor -> ~48 M output samples."""
+    sample: stereo, L = 15 000 000 per channel, same window/factor -> ~240 M output samples
+    (about 15 s of CPU work)."""
     import numpy as np
 
     from oracle import cbind as oc
     from oracle import oracle_np as onp
 
-    length = 3_000_000
+    length = 15_000_000
     x = np.stack([onp.synth_input(c, length) for c in range(CHANNELS)])
     t0 = time.perf_counter()
     y = oc.stretch_offline(x, WINDOW, FACTOR, 1.0, PITCH, seed=SEED, sample_rate=SAMPLE_RATE)

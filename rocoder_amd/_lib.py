@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librocoder_hip.so")
+LIB_PATH = os.environ.get("ROCODER_HIP_LIB") or os.path.join(_HERE, "librocoder_hip.so")
 
 RC_OK, RC_WOULD_BLOCK = 0, 1
 RC_EINVAL, RC_ENODEVICE, RC_EUNSUPPORTED, RC_ENOMEM, RC_EHIP, RC_ECAPACITY = -1, -2, -3, -4, -5, -6

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <new>
@@ -273,8 +274,36 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         p.hop_first = hop_first;
         p.hop_count = hop_count;
         plan_runs(e, n_channels, hop_count, &p.runs_per_channel, &p.run_len);
+#ifdef RC_STAMP_DUMP
+        // diagnostic builds only: per-wave phase cycle totals -> $ROCODER_STAMPS (text)
+        const size_t n_dbg = (size_t)p.runs_per_channel * n_channels * 8 * 32;
+        if (int rcd = e->d_spec.reserve(n_dbg * sizeof(unsigned))) return rcd;
+        RC_HIP(hipMemsetAsync(e->d_spec.p, 0, n_dbg * sizeof(unsigned), s));
+        p.spec = (float2 *)e->d_spec.p;
+#endif
         if (timed) RC_HIP(hipEventRecord(e->ev0, s));
         RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FUSED, p, s));
+#ifdef RC_STAMP_DUMP
+        if (const char *path = getenv("ROCODER_STAMPS")) {
+            std::vector<unsigned> h(n_dbg);
+            RC_HIP(hipStreamSynchronize(s));
+            RC_HIP(hipMemcpy(h.data(), e->d_spec.p, n_dbg * sizeof(unsigned), hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(path, "w")) {
+                double sum[32] = {0};
+                size_t nw = 0;
+                for (size_t w = 0; w < n_dbg / 32; ++w) {
+                    bool any = false;
+                    for (int i = 0; i < 32; ++i) any |= h[w * 32 + i] != 0;
+                    if (!any) continue;
+                    nw++;
+                    for (int i = 0; i < 32; ++i) sum[i] += h[w * 32 + i];
+                }
+                fprintf(f, "waves %zu hops %lld run_len %u\n", nw, (long long)hop_count, p.run_len);
+                for (int i = 0; i < 32; ++i) fprintf(f, "phase %2d mean_cycles_per_wave %.0f\n", i, nw ? sum[i] / nw : 0.0);
+                fclose(f);
+            }
+        }
+#endif
         if (timed) {
             RC_HIP(hipEventRecord(e->ev1, s));
             e->stats_valid = true;

@@ -36,16 +36,51 @@ __device__ constexpr float W32_IM[16] = {
     -0.923879504f, -0.980785251f, -1.f, -0.980785251f, -0.923879504f, -0.831469595f,
     -0.707106769f, -0.555570245f, -0.382683426f, -0.195090324f};
 
+// Pointers that arrive inside the by-value HopParams struct are generic (flat) pointers to the
+// compiler; flat loads tie up both memory counters and cannot use SGPR-base addressing. Everything
+// the engine passes is device global memory, so the kernels cast once to address space 1.
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define RC_AS1 __attribute__((address_space(1)))
+using GF = const float RC_AS1 *;    // global const float*
+using GFW = float RC_AS1 *;         // global float*
+using GV2 = const v2f RC_AS1 *;     // global const float2*
+using GV2W = v2f RC_AS1 *;          // global float2*
+__device__ __forceinline__ float2 ldg2(GV2 p) {
+    const v2f t = *p;
+    return make_float2(t.x, t.y);
+}
+__device__ __forceinline__ void stg2(GV2W p, float2 v) {
+    v2f t;
+    t.x = v.x;
+    t.y = v.y;
+    *p = t;
+}
+
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
 constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }
+
+// points per thread for the large windows (tunable: 32 -> 256 threads, 2 waves/SIMD, 3 passes;
+// 16 -> 512 threads, 4 waves/SIMD, 4 passes)
+// Timing-only diagnostic builds (results are wrong): bit 0 = no phase hash/sincos, bit 1 = no global
+// loads/stores, bit 2 = no LDS exchanges/barriers, bit 3 = no butterflies, bit 4 = no middle stage.
+#ifndef RC_ABLATE
+#define RC_ABLATE 0
+#endif
+#ifndef RC_LOADCH
+#define RC_LOADCH 32
+#endif
+#ifndef RC_PMAX
+#define RC_PMAX 32
+#endif
 
 template <int LOG2N>
 struct Geo {
     static constexpr int m = LOG2N - 1;        // log2 of complex length
     static constexpr int M = 1 << m;           // complex points
     static constexpr int N = 2 * M;            // window length
-    static constexpr int T = cmax(M / 32, cmin(64, M / 4));  // threads per workgroup
+    static constexpr int T = cmax(M / RC_PMAX, cmin(64, M / 4));  // threads per workgroup
+    static constexpr int WPS = T >= 512 ? 4 : 2;  // waves per SIMD the register budget targets
     static constexpr int P = M / T;            // points per thread
     static constexpr int B = clog2(P);         // index bits per pass
     static constexpr int LDS_FLOAT2 = M + (M >> 5) + 1;
@@ -81,11 +116,13 @@ constexpr int lds_reg_off(int q) { return pad_idx(pos_of<B, LO>(0, q)); }
 
 template <class G, int LO>
 __device__ __forceinline__ void lds_store(const float2 (&v)[G::P], float2 *lds, int base) {
+    if (RC_ABLATE & 4) return;
 #pragma unroll
     for (int q = 0; q < G::P; ++q) lds[base + lds_reg_off<G::B, LO>(q)] = v[q];
 }
 template <class G, int LO>
 __device__ __forceinline__ void lds_load(float2 (&v)[G::P], const float2 *lds, int base) {
+    if (RC_ABLATE & 4) return;
 #pragma unroll
     for (int q = 0; q < G::P; ++q) v[q] = lds[base + lds_reg_off<G::B, LO>(q)];
 }
@@ -94,6 +131,35 @@ __device__ __forceinline__ void lds_load(float2 (&v)[G::P], const float2 *lds, i
 // loads, slot addresses) out of the hop loop into hundreds of live VGPRs.
 __device__ __forceinline__ void opaque(float2 &x) { asm volatile("" : "+v"(x.x), "+v"(x.y)); }
 __device__ __forceinline__ void opaque(int &x) { asm volatile("" : "+v"(x)); }
+
+// Diagnostic phase stamps (RC_STAMP builds only; never in the product build): per-wave cycle totals
+// per phase id, written to the debug buffer passed in HopParams::spec.
+#ifndef RC_STAMP
+#define RC_STAMP 0
+#endif
+struct Stamps {
+#if RC_STAMP
+    unsigned long long last;
+    unsigned acc[32];
+    __device__ __forceinline__ void init() {
+        for (int i = 0; i < 32; ++i) acc[i] = 0;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void mark(int id) {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        acc[id] += (unsigned)(t - last);
+        last = t;
+    }
+#else
+    __device__ __forceinline__ void init() {}
+    __device__ __forceinline__ void mark(int) {}
+#endif
+};
 
 // Per-thread state that is worth keeping in registers across the hops of a run.
 template <class G>
@@ -115,16 +181,17 @@ __device__ __forceinline__ void fill_lds_bases(ThreadCtx<G> &c) {
 // w = exp(-2 pi i (n mod 2^s) / 2^(s+1)) = base_s(thread) * W32^(c * 16 >> r)
 template <class G, int LOR, int S_LO, int S_HI, bool INV>
 __device__ __forceinline__ void run_pass(float2 (&v)[G::P], int tid,
-                                         const float2 *__restrict__ wtab) {
+                                         GV2 wtab) {
     const int l = tid & ((1 << LOR) - 1);
 #pragma unroll
     for (int si = 0; si <= S_HI - S_LO; ++si) {
         const int s = INV ? (S_LO + si) : (S_HI - si);
         const int r = s - LOR;
         const int half = 1 << r;
+        if (RC_ABLATE & 8) continue;
         float2 base = make_float2(1.f, 0.f);
         if (LOR > 0) {
-            base = wtab[l << (G::m - 1 - s)];
+            base = ldg2(wtab + (l << (G::m - 1 - s)));
             opaque(base);
         }
 #pragma unroll
@@ -170,41 +237,47 @@ __device__ __forceinline__ void run_pass(float2 (&v)[G::P], int tid,
 }
 
 // forward passes, high bits first. On return v is in register layout last_lor.
-template <class G, int PREV, int PREV_LOR, bool FIRST>
+template <class G, int PREV, int PREV_LOR, bool FIRST, int SID = 1>
 __device__ __forceinline__ void forward_passes(float2 (&v)[G::P], float2 *lds,
                                                const ThreadCtx<G> &c,
-                                               const float2 *__restrict__ wtab) {
+                                               GV2 wtab, Stamps &st) {
     if constexpr (PREV > 0) {
         constexpr int lo = lo_of<G>(PREV);
         constexpr int LOR = lor_of<G>(PREV);
         if constexpr (!FIRST) {
             lds_store<G, PREV_LOR>(v, lds, c.lb[PREV_LOR]);
-            __syncthreads();
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            st.mark(SID);
             lds_load<G, LOR>(v, lds, c.lb[LOR]);
-            __syncthreads();
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            st.mark(SID + 1);
         }
         run_pass<G, LOR, lo, PREV - 1, false>(v, c.tid, wtab);
-        forward_passes<G, lo, LOR, false>(v, lds, c, wtab);
+        st.mark(SID + 2);
+        forward_passes<G, lo, LOR, false, SID + 3>(v, lds, c, wtab, st);
     }
 }
 
 // inverse passes, low bits first. Expects v loaded in layout last_lor; returns layout LO0.
-template <class G, int PREV>
+template <class G, int PREV, int SID = 16>
 __device__ __forceinline__ void inverse_passes(float2 (&v)[G::P], float2 *lds,
                                                const ThreadCtx<G> &c,
-                                               const float2 *__restrict__ wtab) {
+                                               GV2 wtab, Stamps &st) {
     if constexpr (PREV > 0) {
         constexpr int lo = lo_of<G>(PREV);
         constexpr int LOR = lor_of<G>(PREV);
         if constexpr (lo > 0) {
-            inverse_passes<G, lo>(v, lds, c, wtab);
+            inverse_passes<G, lo, SID + 3>(v, lds, c, wtab, st);
             constexpr int LOR_DEEPER = lor_of<G>(lo);
             lds_store<G, LOR_DEEPER>(v, lds, c.lb[LOR_DEEPER]);
-            __syncthreads();
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            st.mark(SID);
             lds_load<G, LOR>(v, lds, c.lb[LOR]);
-            __syncthreads();
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            st.mark(SID + 1);
         }
         run_pass<G, LOR, lo, PREV - 1, true>(v, c.tid, wtab);
+        st.mark(SID + 2);
     }
 }
 
@@ -229,6 +302,11 @@ __device__ __forceinline__ PhaseKey make_phase_key(uint64_t seed_mixed, uint32_t
 // returns (-cos theta, -sin theta), theta = pi * (h >> 9) * 2^-23:
 // v_cos/v_sin take revolutions; f = 0.5 + (h>>9) 2^-24 in [0.5, 1) => 2 pi f = pi + theta.
 __device__ __forceinline__ void phase_ncs(PhaseKey k, uint32_t bin, float &nc, float &ns) {
+    if (RC_ABLATE & 1) {
+        nc = __uint_as_float(0x3F000000u | (bin + k.k0));
+        ns = nc + 1.0f;
+        return;
+    }
     uint32_t x = bin * k.mul + k.k0;
     x ^= x >> 16;
     x *= 0x21F0AAADu;
@@ -284,14 +362,14 @@ __device__ __forceinline__ float cabs_fast(float2 z) {
 // pA / pB: padded LDS indices of bins ja and M - ja
 template <int LOG2N, int MODE>
 __device__ __forceinline__ void do_pair(float2 *lds, int pA, int pB, float2 w, uint32_t ja,
-                                        PhaseKey key, float2 *__restrict__ spec) {
+                                        PhaseKey key, GV2W spec) {
     constexpr uint32_t N = 1u << LOG2N, M = N / 2;
     float2 VA, VB;
     if constexpr (MODE == MODE_RESYNTH) {
-        const float m1a = cabs_fast(spec[ja]);
-        const float m1b = cabs_fast(spec[(N - ja) & (N - 1)]);
-        const float m2a = cabs_fast(spec[M - ja]);
-        const float m2b = cabs_fast(spec[(M + ja) & (N - 1)]);
+        const float m1a = cabs_fast(ldg2(spec + ja));
+        const float m1b = cabs_fast(ldg2(spec + ((N - ja) & (N - 1))));
+        const float m2a = cabs_fast(ldg2(spec + (M - ja)));
+        const float m2b = cabs_fast(ldg2(spec + ((M + ja) & (N - 1))));
         pair_synth<LOG2N>(m1a, m1b, m2a, m2b, w, ja, key, -0.5f / (float)N, VA, VB);
         lds[pA] = VA;
         if (pB != pA) lds[pB] = VB;
@@ -303,10 +381,10 @@ __device__ __forceinline__ void do_pair(float2 *lds, int pA, int pB, float2 w, u
         if constexpr (MODE == MODE_FORWARD) {
             const float2 x1 = make_float2(0.5f * X1.x, 0.5f * X1.y);
             const float2 x2 = make_float2(0.5f * X2c.x, 0.5f * X2c.y);
-            spec[ja] = x1;                                                     // X[ja]
-            spec[(N - ja) & (N - 1)] = make_float2(x1.x, ja ? -x1.y : x1.y);   // X[N-ja]
-            spec[M - ja] = make_float2(x2.x, -x2.y);                           // X[M-ja]
-            spec[(M + ja) & (N - 1)] = ja ? x2 : make_float2(x2.x, -x2.y);     // X[M+ja]
+            stg2(spec + ja, x1);                                                       // X[ja]
+            stg2(spec + ((N - ja) & (N - 1)), make_float2(x1.x, ja ? -x1.y : x1.y));   // X[N-ja]
+            stg2(spec + (M - ja), make_float2(x2.x, -x2.y));                           // X[M-ja]
+            stg2(spec + ((M + ja) & (N - 1)), ja ? x2 : make_float2(x2.x, -x2.y));     // X[M+ja]
         } else {
             const float m1 = cabs_fast(X1), m2 = cabs_fast(X2c);
             pair_synth<LOG2N>(m1, m1, m2, m2, w, ja, key, -0.25f / (float)N, VA, VB);
@@ -319,8 +397,7 @@ __device__ __forceinline__ void do_pair(float2 *lds, int pA, int pB, float2 w, u
 // Middle stage on the bit-reversed spectrum in LDS (position p holds bin brev_m(p)).
 template <int LOG2N, int MODE>
 __device__ __forceinline__ void middle_stage(float2 *lds, int tid, PhaseKey key,
-                                             const float2 *__restrict__ rtab,
-                                             float2 *__restrict__ spec) {
+                                             GV2 rtab, GV2W spec) {
     using G = Geo<LOG2N>;
     constexpr int m = G::m, M = G::M;
     opaque(tid);  // slot addresses / twiddles are recomputed per hop instead of living in VGPRs
@@ -332,7 +409,7 @@ __device__ __forceinline__ void middle_stage(float2 *lds, int tid, PhaseKey key,
         const int j2 = M / 2 - j;
         const int p1 = 4 * c;                                              // brev_m(j)
         const int p2 = (int)(__brev((unsigned)j2) >> (32 - m));            // brev_m(M/2 - j)
-        const float2 w = rtab[j];
+        const float2 w = ldg2(rtab + j);
         // pair (j, M-j): positions p1, p2+1 ; pair (M/2-j, M/2+j): positions p2, p1+1
         do_pair<LOG2N, MODE>(lds, pad_idx(p1), pad_idx(p2 + 1), w, (uint32_t)j, key, spec);
         do_pair<LOG2N, MODE>(lds, pad_idx(p2), pad_idx(p1 + 1), make_float2(-w.y, -w.x),
@@ -342,7 +419,7 @@ __device__ __forceinline__ void middle_stage(float2 *lds, int tid, PhaseKey key,
         // bins 0 (+Nyquist) at position 0, M/2 at position 1, pair (M/4, 3M/4) at 2, 3
         do_pair<LOG2N, MODE>(lds, 0, 0, make_float2(1.f, 0.f), 0u, key, spec);
         do_pair<LOG2N, MODE>(lds, 1, 1, make_float2(0.f, -1.f), (uint32_t)(M / 2), key, spec);
-        do_pair<LOG2N, MODE>(lds, 2, 3, rtab[M / 4], (uint32_t)(M / 4), key, spec);
+        do_pair<LOG2N, MODE>(lds, 2, 3, ldg2(rtab + M / 4), (uint32_t)(M / 4), key, spec);
     }
 }
 
@@ -353,21 +430,24 @@ __device__ __forceinline__ void middle_stage(float2 *lds, int tid, PhaseKey key,
 // no per-register 64-bit address VGPRs.
 template <int LOG2N>
 __device__ __forceinline__ void load_hop(float2 (&v)[Geo<LOG2N>::P], const HopParams &p,
-                                         const float *__restrict__ xc,
-                                         const float *__restrict__ xt,
-                                         const float *__restrict__ win, int64_t k, unsigned lane2) {
+                                         GF xc, GF xt, GF win, int64_t k, unsigned lane2) {
     using G = Geo<LOG2N>;
-    const float *__restrict__ src = (k >= p.tail_hop_first)
+    if (RC_ABLATE & 2) {
+#pragma unroll
+        for (int q = 0; q < G::P; ++q) v[q] = make_float2((float)(lane2 + q), (float)(k + q));
+        return;
+    }
+    GF src = (k >= p.tail_hop_first)
                                         ? xt + (k * (int64_t)p.step - p.tail_origin)
                                         : xc + (k * (int64_t)p.step - p.in_origin);
     // chunks of CH registers: bounds the loads in flight (input + window) to 4 CH VGPRs
-    constexpr int CH = G::P < 8 ? G::P : 8;
+    constexpr int CH = G::P < RC_LOADCH ? G::P : RC_LOADCH;
 #pragma unroll
     for (int q0 = 0; q0 < G::P; q0 += CH) {
 #pragma unroll
         for (int q = q0; q < q0 + CH; ++q) {
-            const float *__restrict__ sq = src + 2 * G::T * q;
-            const float *__restrict__ wq = win + 2 * G::T * q;
+            GF sq = src + 2 * G::T * q;
+            GF wq = win + 2 * G::T * q;
             v[q] = make_float2(sq[lane2] * wq[lane2], sq[lane2 + 1] * wq[lane2 + 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -376,14 +456,14 @@ __device__ __forceinline__ void load_hop(float2 (&v)[Geo<LOG2N>::P], const HopPa
 
 // a per-hop opaque copy of a table pointer: keeps the compiler from hoisting 2P table loads
 // out of the hop loop (they are L1/L2 hits; 64+ live VGPRs would halve occupancy)
-template <class Tp>
-__device__ __forceinline__ const Tp *per_hop(const Tp *ptr) {
-    asm volatile("" : "+s"(ptr));
-    return ptr;
+__device__ __forceinline__ GF per_hop(const float *ptr) {
+    GF g = (GF)ptr;
+    asm volatile("" : "+s"(g));
+    return g;
 }
 
 template <int LOG2N, int MODE, bool PITCH1>
-__global__ __launch_bounds__(Geo<LOG2N>::T, 2) void hop_kernel(const HopParams p) {
+__global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(const HopParams p) {
     using G = Geo<LOG2N>;
     constexpr int P = G::P, T = G::T, M = G::M, N = G::N, H = M;
     constexpr int LL = last_lor<G>(G::m);
@@ -398,43 +478,45 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, 2) void hop_kernel(const HopParams p
     int64_t k_end = k_begin + p.run_len;
     if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
     if (k_begin >= k_end) return;
-    const float *__restrict__ xc = p.x + (size_t)ch * p.in_stride;
-    const float *__restrict__ xt = p.xtail + (size_t)ch * p.tail_stride;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
     const unsigned lane2 = 2u * (unsigned)tid;
-    const float2 *__restrict__ wtab = p.wtab;
-    const float2 *__restrict__ rtab = p.rtab;
+    GV2 wtab = (GV2)p.wtab;
+    GV2 rtab = (GV2)p.rtab;
 
     float2 v[P];
+    Stamps st;
+    st.init();
     if constexpr (MODE == MODE_FORWARD) {
         for (int64_t k = k_begin; k < k_end; ++k) {
-            float2 *spec = p.spec + ((size_t)ch * p.hop_count + (size_t)(k - p.hop_first)) * N;
+            GV2W spec = (GV2W)p.spec + ((size_t)ch * p.hop_count + (size_t)(k - p.hop_first)) * N;
             load_hop<LOG2N>(v, p, xc, xt, per_hop(p.window), k, lane2);
-            forward_passes<G, G::m, 0, true>(v, lds, ctx, wtab);
+            forward_passes<G, G::m, 0, true>(v, lds, ctx, wtab, st);
             lds_store<G, LL>(v, lds, ctx.lb[LL]);
-            __syncthreads();
+            if (!(RC_ABLATE & 4)) __syncthreads();
             middle_stage<LOG2N, MODE_FORWARD>(lds, tid, PhaseKey{0u, 1u}, rtab, spec);
-            __syncthreads();
+            if (!(RC_ABLATE & 4)) __syncthreads();
         }
     } else if constexpr (MODE == MODE_RESYNTH) {
         for (int64_t k = k_begin; k < k_end; ++k) {
             const size_t hop_idx = (size_t)ch * p.hop_count + (size_t)(k - p.hop_first);
-            float2 *spec = p.spec + hop_idx * N;
+            GV2W spec = (GV2W)p.spec + hop_idx * N;
             const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
             middle_stage<LOG2N, MODE_RESYNTH>(lds, tid, key, rtab, spec);
-            __syncthreads();
+            if (!(RC_ABLATE & 4)) __syncthreads();
             lds_load<G, LL>(v, lds, ctx.lb[LL]);
-            __syncthreads();
-            inverse_passes<G, G::m>(v, lds, ctx, wtab);
-            float *y = p.ybuf + hop_idx * N;
-            const float *__restrict__ wsrc = per_hop(p.window);
-            constexpr int CH = P < 8 ? P : 8;
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            inverse_passes<G, G::m>(v, lds, ctx, wtab, st);
+            GFW y = (GFW)p.ybuf + hop_idx * N;
+            GF wsrc = per_hop(p.window);
+            constexpr int CH = P < RC_LOADCH ? P : RC_LOADCH;
 #pragma unroll
             for (int q0 = 0; q0 < P; q0 += CH) {
 #pragma unroll
                 for (int q = q0; q < q0 + CH; ++q)
-                    *reinterpret_cast<float2 *>(y + 2 * T * q + lane2) =
-                        make_float2(v[q].x * (wsrc + 2 * T * q)[lane2],
-                                    v[q].y * (wsrc + 2 * T * q)[lane2 + 1]);
+                    stg2((GV2W)(y + 2 * T * q + lane2),
+                         make_float2(v[q].x * (wsrc + 2 * T * q)[lane2],
+                                     v[q].y * (wsrc + 2 * T * q)[lane2 + 1]));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -444,24 +526,29 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, 2) void hop_kernel(const HopParams p
         float2 tail[PH];
 #pragma unroll
         for (int q = 0; q < PH; ++q) tail[q] = make_float2(0.f, 0.f);
-        float *__restrict__ outc = p.out + (size_t)ch * p.out_stride;
+        GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
         const uint32_t pitch = PITCH1 ? 1u : p.pitch;
         // hop k_begin - 1 is recomputed only for its tail (global hop 0 has a zero predecessor:
         // src/stretcher.rs:58-59)
         for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
             const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
             load_hop<LOG2N>(v, p, xc, xt, per_hop(p.window), k, lane2);
-            forward_passes<G, G::m, 0, true>(v, lds, ctx, wtab);
+            st.mark(0);
+            forward_passes<G, G::m, 0, true>(v, lds, ctx, wtab, st);
             lds_store<G, LL>(v, lds, ctx.lb[LL]);
-            __syncthreads();
-            middle_stage<LOG2N, MODE_FUSED>(lds, tid, key, rtab, nullptr);
-            __syncthreads();
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            st.mark(12);
+            if (!(RC_ABLATE & 16)) middle_stage<LOG2N, MODE_FUSED>(lds, tid, key, rtab, (GV2W) nullptr);
+            st.mark(13);
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            st.mark(14);
             lds_load<G, LL>(v, lds, ctx.lb[LL]);
-            __syncthreads();
-            inverse_passes<G, G::m>(v, lds, ctx, wtab);
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            st.mark(15);
+            inverse_passes<G, G::m>(v, lds, ctx, wtab, st);
             {
-                const float *__restrict__ wsrc = per_hop(p.window);
-                constexpr int CH = P < 8 ? P : 8;
+                GF wsrc = per_hop(p.window);
+                constexpr int CH = P < RC_LOADCH ? P : RC_LOADCH;
 #pragma unroll
                 for (int q0 = 0; q0 < P; q0 += CH) {
 #pragma unroll
@@ -471,12 +558,13 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, 2) void hop_kernel(const HopParams p
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (k >= k_begin) {
+            st.mark(27);
+            if ((RC_ABLATE & 2) ? (v[0].x == 1.2345f) : (k >= k_begin)) {
                 const int64_t g0 = k * (int64_t)H;  // absolute O index of this hop's first sample
-                const float *__restrict__ esrc = per_hop(p.env);
+                GF esrc = per_hop(p.env);
                 if constexpr (PITCH1) {
-                    float *dst = outc + (g0 - p.out_origin);
-                    constexpr int CH = PH < 8 ? PH : 8;
+                    GFW dst = outc + (g0 - p.out_origin);
+                    constexpr int CH = PH < RC_LOADCH ? PH : RC_LOADCH;
 #pragma unroll
                     for (int q0 = 0; q0 < PH; q0 += CH) {
 #pragma unroll
@@ -484,7 +572,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, 2) void hop_kernel(const HopParams p
                             float2 o;  // stretcher.rs:97-100 operation order
                             o.x = (v[q].x + tail[q].x) * (esrc + 2 * T * q)[lane2] * p.amp;
                             o.y = (v[q].y + tail[q].y) * (esrc + 2 * T * q)[lane2 + 1] * p.amp;
-                            *reinterpret_cast<float2 *>(dst + 2 * T * q + lane2) = o;
+                            stg2((GV2W)(dst + 2 * T * q + lane2), o);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -492,7 +580,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, 2) void hop_kernel(const HopParams p
                     // F[t] = O[t p]: keep element g = g0 + i iff g % p == 0, at F[g / p]
                     const int64_t kq = g0 / pitch;
                     const uint32_t kr = (uint32_t)(g0 % pitch);
-                    float *dst = outc + (kq - p.out_origin);
+                    GFW dst = outc + (kq - p.out_origin);
                     int t2 = tid;
                     opaque(t2);
 #pragma unroll
@@ -509,7 +597,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, 2) void hop_kernel(const HopParams p
             }
 #pragma unroll
             for (int q = 0; q < PH; ++q) tail[q] = v[q + PH];
+            st.mark(28);
         }
+#if RC_STAMP
+        if ((tid & 63) == 0 && p.spec) {
+            unsigned *dbg = (unsigned *)p.spec + ((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * 32;
+            for (int i = 0; i < 32; ++i) dbg[i] = st.acc[i];
+        }
+#endif
     }
 }
 
@@ -567,7 +662,7 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
 bool hop_geometry(int log2n, int *threads, size_t *lds_bytes) {
     if (log2n < 5 || log2n > 14) return false;
     const int m = log2n - 1, M = 1 << m;
-    const int T = cmax(M / 32, cmin(64, M / 4));
+    const int T = cmax(M / RC_PMAX, cmin(64, M / 4));
     if (threads) *threads = T;
     if (lds_bytes) *lds_bytes = sizeof(float2) * (size_t)(M + (M >> 5) + 1);
     return true;
