@@ -67,6 +67,12 @@ constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }
 #ifndef RC_ABLATE
 #define RC_ABLATE 0
 #endif
+// Two workgroups share a CU and run identical code: left alone they execute in lockstep (both in
+// their LDS/global wait phases, then both contending for the SIMDs). RC_STAGGER delays every other
+// workgroup by that many s_sleep(127) (8128 cycles each) once, so one computes while the other waits.
+#ifndef RC_STAGGER
+#define RC_STAGGER 0
+#endif
 #ifndef RC_LOADCH
 #define RC_LOADCH 32
 #endif
@@ -100,6 +106,77 @@ template <class G> constexpr int last_lor(int prev) {
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// ---- hand-packed complex arithmetic (v_pk_*_f32 with op_sel / neg modifiers, no shuffles) -------
+// A lone wave issues one VALU op per ~4.6 cycles whether it is packed or not (profiles/
+// r01_ubench_instruction_rates.txt), so packing (re,im) halves the time a wave needs per butterfly
+// whenever its SIMD partner is waiting on LDS / memory.
+#ifndef RC_PK
+#define RC_PK 1
+#endif
+__device__ __forceinline__ v2f to_v(float2 a) {
+    v2f r;
+    r.x = a.x;
+    r.y = a.y;
+    return r;
+}
+__device__ __forceinline__ float2 to_f2(v2f a) { return make_float2(a.x, a.y); }
+// a * w (complex)
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f w) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * k, k a compile-time constant kept in an SGPR pair
+__device__ __forceinline__ v2f pk_cmul_k(v2f a, v2f k) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(k));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=v"(r) : "v"(a), "s"(k), "v"(t));
+    return r;
+}
+// a + conj(w) * b
+__device__ __forceinline__ v2f pk_cmla_conj(v2f a, v2f w, v2f b) {
+    v2f t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(b), "v"(w), "v"(a));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=v"(r) : "v"(b), "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ v2f pk_cmla_conj_k(v2f a, v2f k, v2f b) {
+    v2f t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(b), "s"(k), "v"(a));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=v"(r) : "v"(b), "s"(k), "v"(t));
+    return r;
+}
+// 2a - r
+__device__ __forceinline__ v2f pk_2a_minus(v2f a, v2f r) {
+    v2f o;
+    const v2f two = {2.0f, 2.0f};
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(o) : "v"(a), "s"(two), "v"(r));
+    return o;
+}
+// (a - b) * (-i) = (a.y - b.y, b.x - a.x)
+__device__ __forceinline__ v2f pk_sub_mul_mi(v2f a, v2f b) {
+    v2f o;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]"
+        : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+// a + i b = (a.x - b.y, a.y + b.x) ; a - i b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ v2f pk_add_ib(v2f a, v2f b) {
+    v2f o;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+__device__ __forceinline__ v2f pk_sub_ib(v2f a, v2f b) {
+    v2f o;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b));
+    return o;
 }
 
 constexpr int pad_idx(int n) { return n + (n >> 5); }
@@ -201,6 +278,45 @@ __device__ __forceinline__ void run_pass(float2 (&v)[G::P], int tid,
             const int c = q0 & (half - 1);
             const int kidx = c * (16 >> r);
             const float2 a = v[q0], b = v[q1];
+#if RC_PK
+            const v2f av = to_v(a), bv = to_v(b);
+            const v2f kc = {W32_RE[kidx & 15], W32_IM[kidx & 15]};
+            if (LOR == 0 && c == 0) {  // w = 1
+                v[q0] = to_f2(av + bv);
+                v[q1] = to_f2(av - bv);
+            } else if (LOR == 0 && kidx == 8) {  // w = -i
+                if (!INV) {
+                    v[q0] = to_f2(av + bv);
+                    v[q1] = to_f2(pk_sub_mul_mi(av, bv));
+                } else {
+                    v[q0] = to_f2(pk_add_ib(av, bv));
+                    v[q1] = to_f2(pk_sub_ib(av, bv));
+                }
+            } else if (LOR == 0) {  // compile-time twiddle in an SGPR pair
+                if (!INV) {
+                    v[q0] = to_f2(av + bv);
+                    v[q1] = to_f2(pk_cmul_k(av - bv, kc));
+                } else {
+                    const v2f rv = pk_cmla_conj_k(av, kc, bv);
+                    v[q0] = to_f2(rv);
+                    v[q1] = to_f2(pk_2a_minus(av, rv));
+                }
+            } else {
+                v2f w;
+                const v2f bs = to_v(base);
+                if (c == 0) w = bs;
+                else if (kidx == 8) w = v2f{base.y, -base.x};
+                else w = pk_cmul_k(bs, kc);
+                if (!INV) {
+                    v[q0] = to_f2(av + bv);
+                    v[q1] = to_f2(pk_cmul(av - bv, w));
+                } else {
+                    const v2f rv = pk_cmla_conj(av, w, bv);
+                    v[q0] = to_f2(rv);
+                    v[q1] = to_f2(pk_2a_minus(av, rv));
+                }
+            }
+#else
             if (LOR == 0 && c == 0) {  // w = 1
                 v[q0] = make_float2(a.x + b.x, a.y + b.y);
                 v[q1] = make_float2(a.x - b.x, a.y - b.y);
@@ -232,6 +348,7 @@ __device__ __forceinline__ void run_pass(float2 (&v)[G::P], int tid,
                     v[q1] = make_float2(fmaf(2.f, a.x, -rx), fmaf(2.f, a.y, -ry));
                 }
             }
+#endif
         }
     }
 }
@@ -308,6 +425,23 @@ __device__ __forceinline__ void phase_ncs(PhaseKey k, uint32_t bin, float &nc, f
         return;
     }
     uint32_t x = bin * k.mul + k.k0;
+    x ^= x >> 16;
+    x *= 0x21F0AAADu;
+    x ^= x >> 15;
+    x *= 0x735A2D97u;
+    x ^= x >> 15;
+    const float f = __uint_as_float(0x3F000000u | (x >> 9));
+    nc = __builtin_amdgcn_cosf(f);
+    ns = __builtin_amdgcn_sinf(f);
+}
+
+// hash finaliser on a prepared counter x = bin * mul + k0 (see phase_ncs)
+__device__ __forceinline__ void phase_ncs_x(uint32_t x, float &nc, float &ns) {
+    if (RC_ABLATE & 1) {
+        nc = __uint_as_float(0x3F000000u | (x & 0xFFFFu));
+        ns = nc + 1.0f;
+        return;
+    }
     x ^= x >> 16;
     x *= 0x21F0AAADu;
     x ^= x >> 15;
@@ -423,6 +557,94 @@ __device__ __forceinline__ void middle_stage(float2 *lds, int tid, PhaseKey key,
     }
 }
 
+// Fused-path middle stage, batched: all slot addresses, twiddle loads and LDS reads are issued up
+// front (v[] is dead here, so there are registers to hold them), then the pairs are computed
+// branch-free; thread 0's slot 0 is computed on a harmless stand-in and written to a spare LDS
+// element, the three special pairs follow under one branch.
+template <int LOG2N>
+__device__ __forceinline__ void middle_fused(float2 *lds, int tid, PhaseKey key, GV2 rtab) {
+    using G = Geo<LOG2N>;
+    constexpr int m = G::m, M = G::M, QN = G::QN;
+    constexpr uint32_t N = 2u * M;
+    constexpr int DUMMY = G::LDS_FLOAT2 - 1;
+    opaque(tid);
+    int ia[QN], ib[QN], ic[QN], id[QN];
+    uint32_t ja[QN];
+    float2 w[QN], A1[QN], A2[QN], B1[QN], B2[QN];
+#pragma unroll
+    for (int s = 0; s < QN; ++s) {
+        int c = tid + G::T * s;
+        if (s == 0) c = c ? c : 1;  // thread 0 / slot 0: stand-in, results go to DUMMY
+        const int j = (int)(__brev((unsigned)(2 * c)) >> (32 - (m - 1)));  // bin in (0, M/4)
+        const int p1 = 4 * c;                                              // brev_m(j)
+        const int p2 = (int)(__brev((unsigned)(M / 2 - j)) >> (32 - m));   // brev_m(M/2 - j)
+        ja[s] = (uint32_t)j;
+        w[s] = ldg2(rtab + j);
+        ia[s] = pad_idx(p1);
+        ib[s] = pad_idx(p1 + 1);
+        ic[s] = pad_idx(p2);
+        id[s] = pad_idx(p2 + 1);
+    }
+#pragma unroll
+    for (int s = 0; s < QN; ++s) {
+        A1[s] = lds[ia[s]];  // bin j
+        A2[s] = lds[ib[s]];  // bin j + M/2
+        B1[s] = lds[ic[s]];  // bin M/2 - j
+        B2[s] = lds[id[s]];  // bin M - j
+    }
+    if (tid == 0) {  // redirect the stand-in's writes (uniform per wave except wave 0)
+        ia[0] = ib[0] = ic[0] = id[0] = DUMMY;
+    }
+    // counters of the four phases of a pair follow from one multiply:
+    //   x(b) = b*mul + k0 ;  x(N-b) = (N*mul + 2 k0) - x(b) ;  x(M-b) = (M*mul + 2 k0) - x(b) ;
+    //   x(M+b) = M*mul + x(b)
+    const uint32_t cN = N * key.mul + 2u * key.k0, cM = M * key.mul + 2u * key.k0, cP = M * key.mul;
+    const float nkappa = -0.25f / (float)N;
+#pragma unroll
+    for (int s = 0; s < QN; ++s) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // h = 0: pair (j, M-j) = (A1, B2), twiddle w ; h = 1: pair (M/2-j, M/2+j) = (B1, A2),
+            // twiddle -i conj(w)
+            const float2 A = h ? B1[s] : A1[s];
+            const float2 Bp = h ? A2[s] : B2[s];
+            const float2 ww = h ? make_float2(-w[s].y, -w[s].x) : w[s];
+            const uint32_t jb = h ? (uint32_t)(M / 2) - ja[s] : ja[s];
+            float2 X1, X2c;
+            pair_analyze(A, Bp, ww, X1, X2c);
+            float m1 = cabs_fast(X1) * nkappa, m2 = cabs_fast(X2c) * nkappa;
+            const uint32_t x1 = jb * key.mul + key.k0;
+            float c1, s1, c2, s2, c3, s3, c4, s4;
+            phase_ncs_x(x1, c1, s1);
+            phase_ncs_x(cN - x1, c2, s2);
+            phase_ncs_x(cM - x1, c3, s3);
+            phase_ncs_x(cP + x1, c4, s4);
+            const float px = m1 * (c1 + c2), py = m1 * (s1 - s2);  // Zs[jb]
+            const float qx = m2 * (c3 + c4), qy = m2 * (s4 - s3);  // conj(Zs[M-jb])
+            const float sx = px + qx, sy = py + qy;
+            const float rx = px - qx, ry = py - qy;
+            const float ux = rx * ww.x + ry * ww.y, uy = ry * ww.x - rx * ww.y;  // U = conj(w) R
+            const float2 VA = make_float2(sx - uy, sy + ux);  // S + iU        -> bin jb
+            const float2 VB = make_float2(sx + uy, ux - sy);  // conj(S - iU)  -> bin M - jb
+            if (h == 0) {
+                lds[ia[s]] = VA;
+                lds[id[s]] = VB;
+            } else {
+                lds[ic[s]] = VA;
+                lds[ib[s]] = VB;
+            }
+        }
+    }
+    if (tid == 0) {
+        // bins 0 (+Nyquist) at position 0, M/2 at position 1, pair (M/4, 3M/4) at 2, 3
+        do_pair<LOG2N, MODE_FUSED>(lds, 0, 0, make_float2(1.f, 0.f), 0u, key, (GV2W) nullptr);
+        do_pair<LOG2N, MODE_FUSED>(lds, 1, 1, make_float2(0.f, -1.f), (uint32_t)(M / 2), key,
+                                   (GV2W) nullptr);
+        do_pair<LOG2N, MODE_FUSED>(lds, 2, 3, ldg2(rtab + M / 4), (uint32_t)(M / 4), key,
+                                   (GV2W) nullptr);
+    }
+}
+
 // a_k[n] = x[k*step + n] * w[n] for this thread's 2P samples (n = tid + T q -> samples 2n, 2n+1).
 // Hops whose window runs past the end of the closed input (zero padding, stretcher.rs:129-132)
 // read from the engine's zero-padded tail copy instead, so there is no per-element bounds test.
@@ -437,21 +659,32 @@ __device__ __forceinline__ void load_hop(float2 (&v)[Geo<LOG2N>::P], const HopPa
         for (int q = 0; q < G::P; ++q) v[q] = make_float2((float)(lane2 + q), (float)(k + q));
         return;
     }
-    GF src = (k >= p.tail_hop_first)
-                                        ? xt + (k * (int64_t)p.step - p.tail_origin)
-                                        : xc + (k * (int64_t)p.step - p.in_origin);
-    // chunks of CH registers: bounds the loads in flight (input + window) to 4 CH VGPRs
-    constexpr int CH = G::P < RC_LOADCH ? G::P : RC_LOADCH;
+    // uniform source pointer: force it into SGPRs (the select may otherwise be done in VALU)
+    const int64_t off = (k >= p.tail_hop_first) ? (k * (int64_t)p.step - p.tail_origin)
+                                                : (k * (int64_t)p.step - p.in_origin);
+    const unsigned long long sa =
+        (unsigned long long)((k >= p.tail_hop_first) ? xt : xc) + (unsigned long long)off * 4ull;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sa);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(sa >> 32));
+    GF src = (GF)(((unsigned long long)hi << 32) | lo);
+    // issue every load of the hop (input + window), then one wait, then the multiplies
+    float xr0[G::P], xr1[G::P], wr0[G::P], wr1[G::P];
 #pragma unroll
-    for (int q0 = 0; q0 < G::P; q0 += CH) {
-#pragma unroll
-        for (int q = q0; q < q0 + CH; ++q) {
-            GF sq = src + 2 * G::T * q;
-            GF wq = win + 2 * G::T * q;
-            v[q] = make_float2(sq[lane2] * wq[lane2], sq[lane2 + 1] * wq[lane2 + 1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    for (int q = 0; q < G::P; ++q) {
+        GF sq = src + 2 * G::T * q;
+        xr0[q] = sq[lane2];
+        xr1[q] = sq[lane2 + 1];
     }
+#pragma unroll
+    for (int q = 0; q < G::P; ++q) {
+        GF wq = win + 2 * G::T * q;
+        wr0[q] = wq[lane2];
+        wr1[q] = wq[lane2 + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < G::P; ++q) v[q] = make_float2(xr0[q] * wr0[q], xr1[q] * wr1[q]);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // a per-hop opaque copy of a table pointer: keeps the compiler from hoisting 2P table loads
@@ -484,6 +717,20 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
     GV2 wtab = (GV2)p.wtab;
     GV2 rtab = (GV2)p.rtab;
 
+    if (RC_STAGGER > 0) {
+        // wave slot of this workgroup's first wave on its SIMD (HW_REG_HW_ID[3:0]): the two
+        // workgroups sharing a CU sit in different slots
+        if (threadIdx.x == 0) {
+            const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+            reinterpret_cast<unsigned *>(lds)[0] = slot;
+        }
+        __syncthreads();
+        const unsigned slot = reinterpret_cast<volatile unsigned *>(lds)[0];
+        __syncthreads();
+        if (slot & 1) {
+            for (int i = 0; i < RC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     float2 v[P];
     Stamps st;
     st.init();
@@ -538,7 +785,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
             lds_store<G, LL>(v, lds, ctx.lb[LL]);
             if (!(RC_ABLATE & 4)) __syncthreads();
             st.mark(12);
-            if (!(RC_ABLATE & 16)) middle_stage<LOG2N, MODE_FUSED>(lds, tid, key, rtab, (GV2W) nullptr);
+            if (!(RC_ABLATE & 16)) middle_fused<LOG2N>(lds, tid, key, rtab);
             st.mark(13);
             if (!(RC_ABLATE & 4)) __syncthreads();
             st.mark(14);
@@ -547,16 +794,18 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
             st.mark(15);
             inverse_passes<G, G::m>(v, lds, ctx, wtab, st);
             {
+                // window loads for the synthesis multiply: all issued, one wait
                 GF wsrc = per_hop(p.window);
-                constexpr int CH = P < RC_LOADCH ? P : RC_LOADCH;
+                float wr0[P], wr1[P];
 #pragma unroll
-                for (int q0 = 0; q0 < P; q0 += CH) {
-#pragma unroll
-                    for (int q = q0; q < q0 + CH; ++q)
-                        v[q] = make_float2(v[q].x * (wsrc + 2 * T * q)[lane2],
-                                           v[q].y * (wsrc + 2 * T * q)[lane2 + 1]);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int q = 0; q < P; ++q) {
+                    wr0[q] = (wsrc + 2 * T * q)[lane2];
+                    wr1[q] = (wsrc + 2 * T * q)[lane2 + 1];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < P; ++q) v[q] = make_float2(v[q].x * wr0[q], v[q].y * wr1[q]);
+                __builtin_amdgcn_sched_barrier(0);
             }
             st.mark(27);
             if ((RC_ABLATE & 2) ? (v[0].x == 1.2345f) : (k >= k_begin)) {
@@ -564,17 +813,19 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
                 GF esrc = per_hop(p.env);
                 if constexpr (PITCH1) {
                     GFW dst = outc + (g0 - p.out_origin);
-                    constexpr int CH = PH < RC_LOADCH ? PH : RC_LOADCH;
+                    float er0[PH], er1[PH];
 #pragma unroll
-                    for (int q0 = 0; q0 < PH; q0 += CH) {
+                    for (int q = 0; q < PH; ++q) {
+                        er0[q] = (esrc + 2 * T * q)[lane2];
+                        er1[q] = (esrc + 2 * T * q)[lane2 + 1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int q = q0; q < q0 + CH; ++q) {
-                            float2 o;  // stretcher.rs:97-100 operation order
-                            o.x = (v[q].x + tail[q].x) * (esrc + 2 * T * q)[lane2] * p.amp;
-                            o.y = (v[q].y + tail[q].y) * (esrc + 2 * T * q)[lane2 + 1] * p.amp;
-                            stg2((GV2W)(dst + 2 * T * q + lane2), o);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                    for (int q = 0; q < PH; ++q) {
+                        float2 o;  // stretcher.rs:97-100 operation order
+                        o.x = (v[q].x + tail[q].x) * er0[q] * p.amp;
+                        o.y = (v[q].y + tail[q].y) * er1[q] * p.amp;
+                        stg2((GV2W)(dst + 2 * T * q + lane2), o);
                     }
                 } else {
                     // F[t] = O[t p]: keep element g = g0 + i iff g % p == 0, at F[g / p]
