@@ -50,6 +50,25 @@ def synth_on_device(torch, device, channels, length):
     return torch.stack(rows).contiguous()
 
 
+def pmc_traffic():
+    """HBM-side bytes per hop-kernel launch from the committed rocprofv3 PMC passes of this same
+    command (profiles/, separate --pmc runs: FETCH_SIZE, WRITE_SIZE in KiB). Per
+    MI355X_MICROARCH.md §HBM, FETCH_SIZE on gfx950 tallies 128-B read requests at 64 B, so the read
+    side is doubled; WRITE_SIZE is exact. Returns (bytes, source) or (None, None)."""
+    import glob
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
+    if not files:
+        return None, None
+    txt = open(files[-1]).read()
+    f = re.search(r"FETCH_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt)
+    w = re.search(r"WRITE_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt)
+    if not (f and w):
+        return None, None
+    return (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0, os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline():
     """Time the oracle (a port of the reference algorithm, 1 thread for all channels) on a bounded
     sample: stereo, L = 15 000 000 per channel, same window/factor -> ~240 M output samples
@@ -144,6 +163,7 @@ def main():
         value = total_samples / dt / 1e6
         algo_bytes = hops_per_step * 4.0 * WINDOW  # 4N read bytes per hop
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic()
         res = {
             "metric": "output Msamples/s, 16384-win f=8 stereo (x CPU-realtime in config)",
             "value": round(value, 1),
@@ -171,7 +191,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "rc::hop_kernel<14,FUSED,pitch1>",
                 "kernel_ms": round(kernel_ms, 4),
                 "hops_per_s": round(hops_per_step / (kernel_ms * 1e-3), 1),
