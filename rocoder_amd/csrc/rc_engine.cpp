@@ -164,6 +164,7 @@ struct rc_engine {
     uint32_t stats_launches = 0;
     float *d_window = nullptr, *d_env = nullptr;
     float2 *d_wtab = nullptr, *d_rtab = nullptr;
+    float2 *d_t1 = nullptr;  // large windows only: exp(-2 pi i j / (N/2)), j <= N/8
     uint64_t seed_mixed = 0;
     int n_cu = 256;
     std::vector<Channel> ch;
@@ -246,7 +247,8 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         const int64_t step = e->par.sample_step_len;
         const int64_t k_last = hop_first + hop_count - 1;
         int64_t k_t = end_abs >= (int64_t)N ? (end_abs - N) / step + 1 : 0;  // first short hop
-        const int64_t k_lo = (!e->cfg.kernel && hop_first > 0) ? hop_first - 1 : hop_first;
+        const bool carries_tail = e->cfg.kernel != nullptr;  // a stateful apply(): no hop is recomputed
+        const int64_t k_lo = (!carries_tail && hop_first > 0) ? hop_first - 1 : hop_first;
         if (k_t < k_lo) k_t = k_lo;
         p.xtail = d_in;
         p.tail_stride = 0;
@@ -270,6 +272,83 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
             p.tail_origin = t0;
             p.tail_hop_first = k_t;
         }
+    }
+    if (e->log2n > 14) {
+        // ---- large windows: quarter FFTs through HBM scratch, then the gather-form overlap-add
+        // with the tail carried in d_tail (chunks of hops bound the scratch).
+        const uint32_t hpw = e->par.hops_per_window;
+        const size_t per_hop = (size_t)N * 12;  // 4 Ms complex + N floats
+        int64_t chunk_max = (int64_t)(((size_t)1 << 30) / (per_hop * n_channels));
+        chunk_max = std::max<int64_t>(hpw, std::min<int64_t>(chunk_max / hpw * hpw, 16384));
+        int rc = e->d_tail.reserve((size_t)e->cfg.channels * H * sizeof(float));
+        if (rc) return rc;
+        if (!e->tail_zeroed) {
+            RC_HIP(hipMemsetAsync(e->d_tail.p, 0, (size_t)e->cfg.channels * H * sizeof(float), s));
+            e->tail_zeroed = true;
+        }
+        if (timed) RC_HIP(hipEventRecord(e->ev0, s));
+        uint32_t launches = 0;
+        auto run_chunk = [&](int64_t k0, int64_t kc, bool tail_only) -> int {
+            int rcc;
+            if ((rcc = e->d_spec.reserve((size_t)n_channels * kc * N * 8))) return rcc;
+            if ((rcc = e->d_ybuf.reserve((size_t)n_channels * kc * N * sizeof(float)))) return rcc;
+            rc::BigParams b{};
+            b.x = p.x;
+            b.in_stride = p.in_stride;
+            b.in_origin = p.in_origin;
+            b.xtail = p.xtail;
+            b.tail_stride = p.tail_stride;
+            b.tail_origin = p.tail_origin;
+            b.tail_hop_first = p.tail_hop_first;
+            b.window = e->d_window;
+            b.wtab_sub = e->d_wtab;
+            b.t1 = e->d_t1;
+            b.rtab = e->d_rtab;
+            b.ysub = (float2 *)e->d_spec.p;
+            b.ybuf = (float *)e->d_ybuf.p;
+            b.step = p.step;
+            b.seed_mixed = p.seed_mixed;
+            b.ch_first = ch_first;
+            b.n_channels = n_channels;
+            b.hop_first = k0;
+            b.hop_count = kc;
+            b.log2n = (uint32_t)e->log2n;
+            for (int stage = 0; stage < 3; ++stage) RC_HIP(rc::launch_big(stage, b, s));
+            rc::OlaParams o{};
+            o.ybuf = (const float *)e->d_ybuf.p;
+            o.tail = (float *)e->d_tail.p + (size_t)ch_first * H;
+            o.out = d_out;
+            o.out_stride = out_stride;
+            o.out_origin = out_origin;
+            o.env = e->d_env;
+            o.amp = e->par.corrected_amp_factor;
+            o.pitch = (uint32_t)e->cfg.pitch_multiple;
+            o.n_channels = n_channels;
+            o.hop_first = k0;
+            o.hop_count = kc;
+            o.log2n = (uint32_t)e->log2n;
+            RC_HIP(rc::launch_ola(o, s, tail_only));
+            launches += tail_only ? 4 : 5;
+            return RC_OK;
+        };
+        // the overlap tail of the hop before the range: recomputed (phases are a pure function of
+        // (seed, c, k, j)), so ranges and streaming batches are independent of call history
+        if (hop_first == 0)
+            RC_HIP(hipMemsetAsync((float *)e->d_tail.p + (size_t)ch_first * H, 0,
+                                  (size_t)n_channels * H * sizeof(float), s));
+        else if ((rc = run_chunk(hop_first - 1, 1, true)))
+            return rc;
+        for (int64_t k0 = hop_first; k0 < hop_first + hop_count; k0 += chunk_max) {
+            const int64_t kc = std::min<int64_t>(chunk_max, hop_first + hop_count - k0);
+            if ((rc = run_chunk(k0, kc, false))) return rc;
+        }
+        if (timed) {
+            RC_HIP(hipEventRecord(e->ev1, s));
+            e->stats_valid = true;
+            e->stats_hops = (uint64_t)hop_count * n_channels;
+            e->stats_launches = launches;
+        }
+        return RC_OK;
     }
     if (!e->cfg.kernel) {
         p.hop_first = hop_first;
@@ -426,8 +505,10 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) {
     int rc = derive(cfg, &par);
     if (rc) return rc;
     const int log2n = ilog2_exact(cfg->window_len);
-    if (log2n < 5 || log2n > 14)
-        return fail(RC_EUNSUPPORTED, "window_len %u: the GPU path supports powers of two in [32, 16384]", cfg->window_len);
+    if (log2n < 5 || log2n > 16)
+        return fail(RC_EUNSUPPORTED, "window_len %u: the GPU path supports powers of two in [32, 65536]", cfg->window_len);
+    if (log2n > 14 && cfg->kernel)
+        return fail(RC_EUNSUPPORTED, "user frequency kernels are limited to window_len <= 16384 on the GPU path for now");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         (void)hipGetLastError();
@@ -454,14 +535,26 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) {
     if (cfg->window) memcpy(w.data(), cfg->window, N * sizeof(float));
     else hanning(N, w.data());                    // src/main.rs:131
     crossfade_comp(H, env.data());                // src/stretcher.rs:56
-    std::vector<float2> wtab(std::max<uint32_t>(1, M / 2)), rtab(M / 4 + 1);
-    for (uint32_t k = 0; k < M / 2; ++k) {        // twiddles in f64, rounded to f32 (as rustfft does)
-        const double a = -2.0 * M_PI * (double)k / (double)M;
+    // twiddles in f64, rounded to f32 (as rustfft does). Windows that fit one workgroup:
+    // wtab = exp(-2 pi i k / M) [M/2], rtab = exp(-2 pi i j / N) [M/4+1]. Larger windows run four
+    // quarter FFTs of Ms = M/4 points: wtab is for Ms, rtab covers j <= Ms/2, t1 = exp(-2 pi i j / M).
+    const bool big = log2n > 14;
+    const uint32_t Mf = big ? M / 4 : M;  // length of the in-LDS FFT
+    std::vector<float2> wtab(std::max<uint32_t>(1, Mf / 2)), rtab(big ? Mf / 2 + 1 : M / 4 + 1), t1;
+    for (uint32_t k = 0; k < Mf / 2; ++k) {
+        const double a = -2.0 * M_PI * (double)k / (double)Mf;
         wtab[k] = make_float2((float)cos(a), (float)sin(a));
     }
-    for (uint32_t j = 0; j <= M / 4; ++j) {
+    for (uint32_t j = 0; j < rtab.size(); ++j) {
         const double a = -2.0 * M_PI * (double)j / (double)N;
         rtab[j] = make_float2((float)cos(a), (float)sin(a));
+    }
+    if (big) {
+        t1.resize(Mf + 1);
+        for (uint32_t j = 0; j <= Mf; ++j) {
+            const double a = -2.0 * M_PI * (double)j / (double)M;
+            t1[j] = make_float2((float)cos(a), (float)sin(a));
+        }
     }
     auto cleanup = [&](int code) {
         rc_engine_destroy(e);
@@ -484,6 +577,10 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) {
     RC_HIP_C(hipMemcpy(e->d_env, env.data(), H * sizeof(float), hipMemcpyHostToDevice));
     RC_HIP_C(hipMemcpy(e->d_wtab, wtab.data(), wtab.size() * sizeof(float2), hipMemcpyHostToDevice));
     RC_HIP_C(hipMemcpy(e->d_rtab, rtab.data(), rtab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    if (big) {
+        RC_HIP_C(hipMalloc((void **)&e->d_t1, t1.size() * sizeof(float2)));
+        RC_HIP_C(hipMemcpy(e->d_t1, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
 #undef RC_HIP_C
     *out = e;
     return RC_OK;
@@ -497,6 +594,7 @@ void rc_engine_destroy(rc_engine *e) {
     if (e->d_env) (void)hipFree(e->d_env);
     if (e->d_wtab) (void)hipFree(e->d_wtab);
     if (e->d_rtab) (void)hipFree(e->d_rtab);
+    if (e->d_t1) (void)hipFree(e->d_t1);
     e->d_in.release();
     e->d_out.release();
     e->d_spec.release();
@@ -702,6 +800,7 @@ int rc_engine_last_kernel_stats(rc_engine *e, float *kernel_ms, uint64_t *hops, 
 
 int rc_engine_forward_fft(rc_engine *e, const float *samples, float *out_reim) {
     if (!e || !samples || !out_reim) return fail(RC_EINVAL, "null argument");
+    if (e->log2n > 14) return fail(RC_EUNSUPPORTED, "single-hop entry points are limited to window_len <= 16384");
     const uint32_t N = e->par.window_len;
     RC_HIP(hipSetDevice(e->device));
     int rc;
@@ -728,6 +827,7 @@ int rc_engine_forward_fft(rc_engine *e, const float *samples, float *out_reim) {
 
 int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float *samples, float *out) {
     if (!e || !samples || !out) return fail(RC_EINVAL, "null argument");
+    if (e->log2n > 14) return fail(RC_EUNSUPPORTED, "single-hop entry points are limited to window_len <= 16384");
     const uint32_t N = e->par.window_len;
     RC_HIP(hipSetDevice(e->device));
     int rc;

@@ -57,12 +57,41 @@ struct OlaParams {
     uint32_t log2n;
 };
 
+// Windows larger than one workgroup's LDS (N = 32768, 65536): the N/2-point FFT is split into
+// four interleaved quarter-length FFTs that DO fit (stage A / C), glued by a radix-4 step fused
+// with the per-bin middle stage (stage B); everything goes through HBM scratch.
+struct BigParams {
+    const float *x;
+    size_t in_stride;
+    int64_t in_origin;
+    const float *xtail;
+    size_t tail_stride;
+    int64_t tail_origin;
+    int64_t tail_hop_first;
+    const float *window;     // [N]
+    const float2 *wtab_sub;  // [Ms/2]   exp(-2 pi i k / Ms), Ms = N/8
+    const float2 *t1;        // [Ms+1]   exp(-2 pi i j / (N/2))
+    const float2 *rtab;      // [Ms/2+1] exp(-2 pi i j / N)
+    float2 *ysub;            // [n_channels][hop_count][4][Ms] scratch: Y_s, then U_s (natural order)
+    float *ybuf;             // [n_channels][hop_count][N] windowed resynthesis y_k
+    uint32_t step;
+    uint64_t seed_mixed;
+    uint32_t ch_first;
+    uint32_t n_channels;
+    int64_t hop_first;
+    int64_t hop_count;
+    uint32_t log2n;          // 15 or 16
+};
+
 enum HopMode { MODE_FUSED = 0, MODE_FORWARD = 1, MODE_RESYNTH = 2 };
 
 // Geometry chosen by the kernels for a window length (threads per workgroup, LDS bytes).
 bool hop_geometry(int log2n, int *threads, size_t *lds_bytes);
 // Launchers. Return hipSuccess or the launch error. log2n in [5, 14].
 hipError_t launch_hop(int log2n, HopMode mode, const HopParams &p, hipStream_t s);
-hipError_t launch_ola(const OlaParams &p, hipStream_t s);
+// tail_only: just save y_{last}[H..] of the chunk as the carried tail (no output written)
+hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only = false);
+// stage 0 = A (forward quarter FFTs), 1 = B (radix-4 + middle + radix-4), 2 = C (inverse quarter FFTs)
+hipError_t launch_big(int stage, const BigParams &p, hipStream_t s);
 
 }  // namespace rc

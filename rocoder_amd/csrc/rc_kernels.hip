@@ -908,6 +908,172 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
+
+// ======================= large windows (N = 32768 / 65536) ===================================
+// z[n] (M = N/2 complex points) = 4 interleaved sequences z_s[n'] = z[4n'+s] of Ms = M/4 points:
+//   Z[r + Ms k1] = sum_s W_M^{s r} (-i)^{s k1} Y_s[r],  Y_s = FFT_Ms(z_s)          (forward)
+//   y[4n'+s]     = IFFT_Ms(U_s)[n'],  U_s[r] = conj(W_M^{s r}) sum_k1 (+i)^{s k1} V[r + Ms k1]
+// Stage A/C reuse the in-LDS passes of the fused kernel on one quarter; stage B is per-bin.
+template <int LOG2NS>  // Geo<LOG2NS>::M == Ms
+__global__ __launch_bounds__(Geo<LOG2NS>::T, 2) void big_a_kernel(const BigParams p) {
+    using G = Geo<LOG2NS>;
+    constexpr int P = G::P, T = G::T, Ms = G::M;
+    constexpr int LL = last_lor<G>(G::m);
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    ThreadCtx<G> ctx;
+    ctx.tid = threadIdx.x;
+    fill_lds_bases<G, G::m>(ctx);
+    const int tid = ctx.tid;
+    const uint32_t sub = blockIdx.x & 3u;
+    const int64_t hop_local = blockIdx.x >> 2;
+    const uint32_t ch = blockIdx.y;
+    const int64_t k = p.hop_first + hop_local;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    GF win = (GF)p.window;
+    GF src = (k >= p.tail_hop_first) ? xt + (k * (int64_t)p.step - p.tail_origin)
+                                     : xc + (k * (int64_t)p.step - p.in_origin);
+    float2 v[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const int i0 = 2 * (4 * (tid + T * q) + (int)sub);  // samples 2n, 2n+1 of z[n], n = 4n'+s
+        v[q] = make_float2(src[i0] * win[i0], src[i0 + 1] * win[i0 + 1]);
+    }
+    Stamps st;
+    st.init();
+    forward_passes<G, G::m, 0, true>(v, lds, ctx, (GV2)p.wtab_sub, st);
+    GV2W y = (GV2W)p.ysub + (((size_t)ch * p.hop_count + (size_t)hop_local) * 4 + sub) * Ms;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const unsigned pos = (unsigned)pos_of<G::B, LL>(tid, q);  // position holds bin brev(pos)
+        stg2(y + (__brev(pos) >> (32 - G::m)), v[q]);
+    }
+}
+
+template <int LOG2NS>
+__global__ __launch_bounds__(Geo<LOG2NS>::T, 2) void big_c_kernel(const BigParams p) {
+    using G = Geo<LOG2NS>;
+    constexpr int P = G::P, T = G::T, Ms = G::M;
+    constexpr int LL = last_lor<G>(G::m);
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    ThreadCtx<G> ctx;
+    ctx.tid = threadIdx.x;
+    fill_lds_bases<G, G::m>(ctx);
+    const int tid = ctx.tid;
+    const uint32_t sub = blockIdx.x & 3u;
+    const int64_t hop_local = blockIdx.x >> 2;
+    const uint32_t ch = blockIdx.y;
+    const size_t hop_idx = (size_t)ch * p.hop_count + (size_t)hop_local;
+    GV2 u = (GV2)p.ysub + (hop_idx * 4 + sub) * Ms;
+    float2 v[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const unsigned pos = (unsigned)pos_of<G::B, LL>(tid, q);
+        v[q] = ldg2(u + (__brev(pos) >> (32 - G::m)));
+    }
+    Stamps st;
+    st.init();
+    inverse_passes<G, G::m>(v, lds, ctx, (GV2)p.wtab_sub, st);
+    GF win = (GF)p.window;
+    GFW y = (GFW)p.ybuf + hop_idx * (size_t)(8 * Ms);
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const int i0 = 2 * (4 * (tid + T * q) + (int)sub);
+        stg2((GV2W)(y + i0), make_float2(v[q].x * win[i0], v[q].y * win[i0 + 1]));
+    }
+}
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmuli(float2 a) { return make_float2(-a.y, a.x); }    // * (+i)
+__device__ __forceinline__ float2 cmulmi(float2 a) { return make_float2(a.y, -a.x); }   // * (-i)
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+// X[k1] = sum_s (-i)^{s k1} a[s]  (SIGN = -1)  or  sum_s (+i)^{s k1} a[s]  (SIGN = +1)
+template <int SIGN>
+__device__ __forceinline__ void radix4(const float2 (&a)[4], float2 (&o)[4]) {
+    const float2 s02 = cadd(a[0], a[2]), d02 = csub(a[0], a[2]);
+    const float2 s13 = cadd(a[1], a[3]), d13 = csub(a[1], a[3]);
+    o[0] = cadd(s02, s13);
+    o[2] = csub(s02, s13);
+    const float2 r = SIGN < 0 ? cmulmi(d13) : cmuli(d13);
+    o[1] = cadd(d02, r);
+    o[3] = csub(d02, r);
+}
+
+// Stage B: one thread per residue pair (k2, Ms - k2), k2 in [0, Ms/2].
+__global__ __launch_bounds__(256) void big_b_kernel(const BigParams p) {
+    const uint32_t N = 1u << p.log2n, M = N / 2, Ms = M / 4;
+    const uint32_t k2 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k2 > Ms / 2) return;
+    const int64_t hop_local = blockIdx.y;
+    const uint32_t ch = blockIdx.z;
+    const int64_t k = p.hop_first + hop_local;
+    const uint32_t r = k2, rp = (Ms - k2) & (Ms - 1);
+    GV2W y = (GV2W)p.ysub + ((size_t)ch * p.hop_count + (size_t)hop_local) * 4 * (size_t)Ms;
+    GV2 t1 = (GV2)p.t1;
+    const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+    float2 wr[4], wp[4], a[4], b[4], Zr[4], Zp[4], Vr[4], Vp[4];
+    wr[0] = wp[0] = make_float2(1.f, 0.f);
+    wr[1] = ldg2(t1 + r);
+    wr[2] = ldg2(t1 + 2 * r);   // 2r <= Ms
+    wr[3] = cmul(wr[1], wr[2]);
+    wp[1] = ldg2(t1 + rp);
+    wp[2] = cmul(wp[1], wp[1]);
+    wp[3] = cmul(wp[1], wp[2]);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a[s] = cmul(wr[s], ldg2((GV2)y + (size_t)s * Ms + r));
+        b[s] = cmul(wp[s], ldg2((GV2)y + (size_t)s * Ms + rp));
+    }
+    radix4<-1>(a, Zr);  // Z[r + Ms k1]
+    radix4<-1>(b, Zp);  // Z[rp + Ms k1]
+    const float2 wbase = ldg2((GV2)p.rtab + k2);  // exp(-2 pi i k2 / N)
+    const float c8 = 0.70710678118654752f;
+    const float2 e8[4] = {make_float2(1.f, 0.f), make_float2(c8, -c8), make_float2(0.f, -1.f),
+                          make_float2(-c8, -c8)};  // exp(-2 pi i k1 / 8)
+    const float nkappa = -0.25f / (float)N;
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+        const uint32_t J = k2 + Ms * (uint32_t)k1;  // partner M - J
+        const float2 A = Zr[k1];
+        const float2 Bp = (k2 == 0) ? Zr[(4 - k1) & 3] : Zp[3 - k1];
+        const float2 w = cmul(wbase, e8[k1]);
+        float2 X1, X2c;
+        pair_analyze(A, Bp, w, X1, X2c);
+        float m1 = cabs_fast(X1) * nkappa, m2 = cabs_fast(X2c) * nkappa;
+        float c1, s1, c2, s2, c3, s3, c4, s4;
+        phase_ncs(key, J, c1, s1);
+        phase_ncs(key, (N - J) & (N - 1), c2, s2);
+        phase_ncs(key, M - J, c3, s3);
+        phase_ncs(key, M + J, c4, s4);
+        const float px = m1 * (c1 + c2), py = m1 * (s1 - s2);
+        const float qx = m2 * (c3 + c4), qy = m2 * (s4 - s3);
+        const float sx = px + qx, sy = py + qy, rx = px - qx, ry = py - qy;
+        const float ux = rx * w.x + ry * w.y, uy = ry * w.x - rx * w.y;
+        Vr[k1] = make_float2(sx - uy, sy + ux);      // V[J]
+        Vp[3 - k1] = make_float2(sx + uy, ux - sy);  // V[M - J] = V[rp + Ms (3 - k1)]   (k2 > 0)
+    }
+    float2 u[4];
+    radix4<+1>(Vr, u);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) stg2(y + (size_t)s * Ms + r, cmul(cconj(wr[s]), u[s]));
+    if (k2 != 0 && 2 * k2 != Ms) {
+        radix4<+1>(Vp, u);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) stg2(y + (size_t)s * Ms + rp, cmul(cconj(wp[s]), u[s]));
+    }
+}
+
+template <int LOG2NS>
+hipError_t launch_big_ac(int stage, const BigParams &p, hipStream_t s) {
+    using G = Geo<LOG2NS>;
+    const dim3 grid((unsigned)(p.hop_count * 4), p.n_channels), block(G::T);
+    const size_t lds = sizeof(float2) * G::LDS_FLOAT2;
+    if (stage == 0) hipLaunchKernelGGL((big_a_kernel<LOG2NS>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((big_c_kernel<LOG2NS>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 bool hop_geometry(int log2n, int *threads, size_t *lds_bytes) {
@@ -935,11 +1101,25 @@ hipError_t launch_hop(int log2n, HopMode mode, const HopParams &p, hipStream_t s
     }
 }
 
-hipError_t launch_ola(const OlaParams &p, hipStream_t s) {
+hipError_t launch_big(int stage, const BigParams &p, hipStream_t s) {
+    if (p.log2n != 15 && p.log2n != 16) return hipErrorInvalidValue;
+    if (stage == 1) {
+        const uint32_t Ms = (1u << p.log2n) / 8;
+        const dim3 grid((Ms / 2 + 1 + 255) / 256, (unsigned)p.hop_count, p.n_channels), block(256);
+        hipLaunchKernelGGL(big_b_kernel, grid, block, 0, s, p);
+        return hipGetLastError();
+    }
+    // quarter FFT of N/8 complex points == the passes of window length N/4
+    return p.log2n == 15 ? launch_big_ac<13>(stage, p, s) : launch_big_ac<14>(stage, p, s);
+}
+
+hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only) {
     const dim3 grid((unsigned)p.hop_count, p.n_channels), block(256);
-    hipLaunchKernelGGL(ola_kernel, grid, block, 0, s, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (!tail_only) {
+        hipLaunchKernelGGL(ola_kernel, grid, block, 0, s, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
     const dim3 g2(4, p.n_channels);
     hipLaunchKernelGGL(ola_save_tail_kernel, g2, block, 0, s, p);
     return hipGetLastError();

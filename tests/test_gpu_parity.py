@@ -99,6 +99,35 @@ def test_edge_lengths(N, L):  # empty / shorter than one window / ragged tails (
         assert np.all(got == 0)
 
 
+@pytest.mark.parametrize("N,L,f,p,ch", [(32768, 200000, 8.0, 1, 2), (65536, 400000, 32.0, 1, 2),
+                                        (65536, 300000, 4.0, 2, 1), (32768, 32768, 1.0, 1, 1),
+                                        (65536, 1000, 2.0, 1, 1)])
+def test_large_windows_match_oracle(N, L, f, p, ch):
+    """BASELINE C5 geometry (window 65536, factor 32): quarter-FFT path through HBM scratch."""
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, L) for c in range(ch)])
+    got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=0xC5)
+    ref = oc.stretch_offline(x, N, f, 1.0, p, seed=0xC5)
+    for c in range(ch):
+        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}")
+
+
+def test_large_window_streaming_equals_offline():
+    ra = _engine_mod()
+    x = onp.synth_input(0, 500000)
+    w = oc.hanning(65536)
+    q: "queue.Queue" = queue.Queue()
+    s = ra.Stretcher(ra.AudioSpec(1, 44100), q, 16.0, 1.0, 1, w, seed=8)
+    for i in range(0, x.size, 70001):
+        q.put(x[i:i + 70001])
+    q.put(None)
+    wins = []
+    while not s.is_done():
+        wins.append(s.next_window().copy())
+    ref = oc.stretch_offline(x[None], 65536, 16.0, 1.0, 1, seed=8)[0]
+    assert_parity(np.concatenate(wins), ref, "N=65536 streaming")
+
+
 def test_zero_input_gives_zero_output():
     ra = _engine_mod()
     got = ra.stretch(np.zeros((2, 40000), np.float32), window_len=4096, factor=8.0, seed=3)
@@ -293,6 +322,28 @@ def test_window_ranges_concatenate_to_full_output():
             assert torch.equal(out, full), f"world={world}"  # bit-exact: same hops, same kernel
 
 
+def test_large_window_ranges_concatenate_to_full_output():
+    import torch
+
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, 400000) for c in range(2)])
+    xt = torch.from_numpy(x).cuda()
+    with ra.Engine(window_len=32768, factor=8.0, channels=2, seed=6) as e:
+        full = e.stretch_tensor(xt)
+        wout = e.params.window_out_len
+        nwin = full.shape[1] // wout
+        from rocoder_amd.distributed import engine_compute, shard_plan
+
+        comp = engine_compute(e, xt)
+        for world in (2, 3, 8):
+            out = torch.zeros_like(full)
+            for s in reversed(shard_plan(2, nwin, world)):  # any order: ranges are stateless
+                out[s.ch_first:s.ch_first + s.ch_count,
+                    s.win_first * wout:(s.win_first + s.win_count) * wout] = comp(s)
+            torch.cuda.synchronize()
+            assert torch.equal(out, full), f"world={world}"
+
+
 # ------------------------------------------------------------------ BASELINE sizes, properties
 def _spot_check(ra, out, x, N, f, p, seed, hops, c):
     """O[kH+i] = (y_k[i] + y_{k-1}[H+i]) env[i] amp, F = O[::p] — checked with the oracle's ReFFT
@@ -344,6 +395,37 @@ def test_baseline_config_full_size(p):
         out2 = e.stretch_tensor(xt)
         torch.cuda.synchronize()
         assert torch.equal(out, out2)
+
+
+def test_baseline_c5_full_size():
+    """BASELINE C5: 8 channels, window 65536, factor 32, L = 5 292 000 per channel — here all eight
+    channels on one GPU through the same shard plan the 8-GPU run uses (one channel per rank)."""
+    import torch
+
+    ra = _engine_mod()
+    from rocoder_amd.distributed import engine_compute, shard_plan
+
+    N, f, L, seed, C = 65536, 32.0, 5_292_000, 0x5EED, 8
+    x = np.stack([onp.synth_input(c, L) for c in range(C)])
+    xt = torch.from_numpy(x).cuda()
+    with ra.Engine(window_len=N, factor=f, channels=C, seed=seed) as e:
+        n_out = e.output_len(L)
+        assert n_out == 167_313_408
+        wout = e.params.window_out_len
+        nwin = n_out // wout
+        comp = engine_compute(e, xt)
+        plan = shard_plan(C, nwin, 8)
+        assert [(s.ch_first, s.ch_count, s.win_count) for s in plan] == [(c, 1, nwin) for c in range(C)]
+        K = n_out // (N // 2)
+        rng = np.random.default_rng(5)
+        for s in plan:
+            seg = comp(s)
+            torch.cuda.synchronize()
+            o = seg[0].cpu().numpy()
+            assert np.isfinite(o).all()
+            ks = sorted({0, 1, K - 1, int(rng.integers(2, K - 2))})
+            _spot_check(ra, o, x[s.ch_first], N, f, 1, seed, ks, s.ch_first)
+            del seg
 
 
 def test_unsupported_configs_fail_loudly():
