@@ -211,15 +211,14 @@ rc::HopParams base_params(const rc_engine *e) {
     p.rtab = e->d_rtab;
     p.amp = e->par.corrected_amp_factor;
     p.step = e->par.sample_step_len;
-    p.pitch = (uint32_t)e->cfg.pitch_multiple;
+    p.pitch = (uint32_t)std::max(1, e->cfg.pitch_multiple);
     p.seed_mixed = e->seed_mixed;
     p.stagger_div = (uint32_t)std::max(1, e->n_cu);
     return p;
 }
 
 int check_gpu_path(const rc_engine *e) {
-    if (e->cfg.pitch_multiple < 1)
-        return fail(RC_EUNSUPPORTED, "negative pitch multiples (resample_slower, src/resampler.rs:20-35) are not on the GPU path yet");
+    (void)e;
     return RC_OK;
 }
 
@@ -273,84 +272,8 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
             p.tail_hop_first = k_t;
         }
     }
-    if (e->log2n > 14) {
-        // ---- large windows: quarter FFTs through HBM scratch, then the gather-form overlap-add
-        // with the tail carried in d_tail (chunks of hops bound the scratch).
-        const uint32_t hpw = e->par.hops_per_window;
-        const size_t per_hop = (size_t)N * 12;  // 4 Ms complex + N floats
-        int64_t chunk_max = (int64_t)(((size_t)1 << 30) / (per_hop * n_channels));
-        chunk_max = std::max<int64_t>(hpw, std::min<int64_t>(chunk_max / hpw * hpw, 16384));
-        int rc = e->d_tail.reserve((size_t)e->cfg.channels * H * sizeof(float));
-        if (rc) return rc;
-        if (!e->tail_zeroed) {
-            RC_HIP(hipMemsetAsync(e->d_tail.p, 0, (size_t)e->cfg.channels * H * sizeof(float), s));
-            e->tail_zeroed = true;
-        }
-        if (timed) RC_HIP(hipEventRecord(e->ev0, s));
-        uint32_t launches = 0;
-        auto run_chunk = [&](int64_t k0, int64_t kc, bool tail_only) -> int {
-            int rcc;
-            if ((rcc = e->d_spec.reserve((size_t)n_channels * kc * N * 8))) return rcc;
-            if ((rcc = e->d_ybuf.reserve((size_t)n_channels * kc * N * sizeof(float)))) return rcc;
-            rc::BigParams b{};
-            b.x = p.x;
-            b.in_stride = p.in_stride;
-            b.in_origin = p.in_origin;
-            b.xtail = p.xtail;
-            b.tail_stride = p.tail_stride;
-            b.tail_origin = p.tail_origin;
-            b.tail_hop_first = p.tail_hop_first;
-            b.window = e->d_window;
-            b.wtab_sub = e->d_wtab;
-            b.t1 = e->d_t1;
-            b.rtab = e->d_rtab;
-            b.ysub = (float2 *)e->d_spec.p;
-            b.ybuf = (float *)e->d_ybuf.p;
-            b.step = p.step;
-            b.seed_mixed = p.seed_mixed;
-            b.ch_first = ch_first;
-            b.n_channels = n_channels;
-            b.hop_first = k0;
-            b.hop_count = kc;
-            b.log2n = (uint32_t)e->log2n;
-            for (int stage = 0; stage < 3; ++stage) RC_HIP(rc::launch_big(stage, b, s));
-            rc::OlaParams o{};
-            o.ybuf = (const float *)e->d_ybuf.p;
-            o.tail = (float *)e->d_tail.p + (size_t)ch_first * H;
-            o.out = d_out;
-            o.out_stride = out_stride;
-            o.out_origin = out_origin;
-            o.env = e->d_env;
-            o.amp = e->par.corrected_amp_factor;
-            o.pitch = (uint32_t)e->cfg.pitch_multiple;
-            o.n_channels = n_channels;
-            o.hop_first = k0;
-            o.hop_count = kc;
-            o.log2n = (uint32_t)e->log2n;
-            RC_HIP(rc::launch_ola(o, s, tail_only));
-            launches += tail_only ? 4 : 5;
-            return RC_OK;
-        };
-        // the overlap tail of the hop before the range: recomputed (phases are a pure function of
-        // (seed, c, k, j)), so ranges and streaming batches are independent of call history
-        if (hop_first == 0)
-            RC_HIP(hipMemsetAsync((float *)e->d_tail.p + (size_t)ch_first * H, 0,
-                                  (size_t)n_channels * H * sizeof(float), s));
-        else if ((rc = run_chunk(hop_first - 1, 1, true)))
-            return rc;
-        for (int64_t k0 = hop_first; k0 < hop_first + hop_count; k0 += chunk_max) {
-            const int64_t kc = std::min<int64_t>(chunk_max, hop_first + hop_count - k0);
-            if ((rc = run_chunk(k0, kc, false))) return rc;
-        }
-        if (timed) {
-            RC_HIP(hipEventRecord(e->ev1, s));
-            e->stats_valid = true;
-            e->stats_hops = (uint64_t)hop_count * n_channels;
-            e->stats_launches = launches;
-        }
-        return RC_OK;
-    }
-    if (!e->cfg.kernel) {
+    const bool fused = !e->cfg.kernel && e->log2n <= 14 && e->cfg.pitch_multiple >= 1;
+    if (fused) {
         p.hop_first = hop_first;
         p.hop_count = hop_count;
         plan_runs(e, n_channels, hop_count, &p.runs_per_channel, &p.run_len);
@@ -392,51 +315,89 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         }
         return RC_OK;
     }
-    // ---- user frequency kernel: forward -> host apply() per hop -> resynth -> overlap-add.
-    // The overlap tail is carried in d_tail across chunks/calls (apply() may be stateful, so a
-    // hop is never recomputed). Hops are presented to apply() in the reference's order: windows
-    // outer, channels inner (src/stretcher_processor.rs:63-70), hops innermost.
+    // ---- unfused pipeline: y_k for a chunk of hops lands in HBM scratch, then a gather-form
+    // overlap-add kernel writes the output. Used for
+    //   * a user frequency kernel: forward -> host apply() per hop -> resynth. apply() may be
+    //     stateful, so no hop is ever recomputed: the overlap tail is carried in d_tail across
+    //     chunks and calls, and hops reach apply() in the reference's order (windows outer, channels
+    //     inner: src/stretcher_processor.rs:63-70; hops innermost);
+    //   * windows of 32768 / 65536 samples: four quarter FFTs through scratch (rc::launch_big);
+    //   * negative pitch multiples: linear-interpolating overlap-add (src/resampler.rs:20-35).
+    // Without a user kernel the hop before the range is recomputed to seed the tail, so ranges and
+    // streaming batches do not depend on call history.
+    const bool big = e->log2n > 14;
     const uint32_t hpw = e->par.hops_per_window;
-    const int64_t chunk_max = std::max<int64_t>(hpw, (int64_t)(((size_t)192 << 20) / ((size_t)N * 8 * n_channels)) / hpw * hpw);
+    const size_t per_hop = (size_t)N * (big ? 12 : 12);  // spectrum / quarter-FFT scratch + y
+    int64_t chunk_max = (int64_t)((((size_t)(e->cfg.kernel ? 192 : 1024)) << 20) / (per_hop * n_channels));
+    chunk_max = std::max<int64_t>(hpw, std::min<int64_t>(chunk_max / hpw * hpw, 32768));
     int rc = e->d_tail.reserve((size_t)e->cfg.channels * H * sizeof(float));
     if (rc) return rc;
     if (!e->tail_zeroed) {
         RC_HIP(hipMemsetAsync(e->d_tail.p, 0, (size_t)e->cfg.channels * H * sizeof(float), s));
         e->tail_zeroed = true;
     }
-    if (hop_first == 0)  // a fresh stream starts from H zeros (src/stretcher.rs:58-59)
-        RC_HIP(hipMemsetAsync((float *)e->d_tail.p + (size_t)ch_first * H, 0,
-                              (size_t)n_channels * H * sizeof(float), s));
-    for (int64_t k0 = hop_first; k0 < hop_first + hop_count; k0 += chunk_max) {
-        const int64_t kc = std::min<int64_t>(chunk_max, hop_first + hop_count - k0);
+    uint32_t launches = 0;
+    auto run_chunk = [&](int64_t k0, int64_t kc, bool tail_only) -> int {
+        int rcc;
         const size_t spec_floats = (size_t)n_channels * kc * N * 2;
-        if ((rc = e->d_spec.reserve(spec_floats * sizeof(float)))) return rc;
-        if ((rc = e->d_ybuf.reserve((size_t)n_channels * kc * N * sizeof(float)))) return rc;
-        p.spec = (float2 *)e->d_spec.p;
-        p.ybuf = (float *)e->d_ybuf.p;
-        p.hop_first = k0;
-        p.hop_count = kc;
-        plan_runs(e, n_channels, kc, &p.runs_per_channel, &p.run_len);
-        RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, p, s));
-        e->h_spec.resize(spec_floats);
-        e->h_spec2.resize((size_t)N * 2);
-        RC_HIP(hipMemcpyAsync(e->h_spec.data(), e->d_spec.p, spec_floats * sizeof(float),
-                              hipMemcpyDeviceToHost, s));
-        RC_HIP(hipStreamSynchronize(s));
-        for (int64_t w0 = 0; w0 < kc; w0 += hpw) {
-            for (uint32_t c = 0; c < n_channels; ++c) {
-                for (int64_t h = w0; h < std::min<int64_t>(w0 + hpw, kc); ++h) {
-                    float *sp = e->h_spec.data() + ((size_t)c * kc + h) * N * 2;
-                    // src/fft.rs:86-99: copy in, call apply(now_ms, bins), copy out
-                    const int krc = e->cfg.kernel(now_ms(e), sp, e->h_spec2.data(), N, e->cfg.kernel_user);
-                    if (krc == 0) memcpy(sp, e->h_spec2.data(), (size_t)N * 2 * sizeof(float));
-                    // non-zero == panic: keep the unmodified spectrum (src/fft.rs:100-106)
+        if ((rcc = e->d_spec.reserve(spec_floats * sizeof(float)))) return rcc;
+        if ((rcc = e->d_ybuf.reserve((size_t)n_channels * kc * N * sizeof(float)))) return rcc;
+        if (big) {
+            rc::BigParams b{};
+            b.x = p.x;
+            b.in_stride = p.in_stride;
+            b.in_origin = p.in_origin;
+            b.xtail = p.xtail;
+            b.tail_stride = p.tail_stride;
+            b.tail_origin = p.tail_origin;
+            b.tail_hop_first = p.tail_hop_first;
+            b.window = e->d_window;
+            b.wtab_sub = e->d_wtab;
+            b.t1 = e->d_t1;
+            b.rtab = e->d_rtab;
+            b.ysub = (float2 *)e->d_spec.p;
+            b.ybuf = (float *)e->d_ybuf.p;
+            b.step = p.step;
+            b.seed_mixed = p.seed_mixed;
+            b.ch_first = ch_first;
+            b.n_channels = n_channels;
+            b.hop_first = k0;
+            b.hop_count = kc;
+            b.log2n = (uint32_t)e->log2n;
+            for (int stage = 0; stage < 3; ++stage) RC_HIP(rc::launch_big(stage, b, s));
+            launches += 3;
+        } else {
+            rc::HopParams q = p;
+            q.spec = (float2 *)e->d_spec.p;
+            q.ybuf = (float *)e->d_ybuf.p;
+            q.hop_first = k0;
+            q.hop_count = kc;
+            plan_runs(e, n_channels, kc, &q.runs_per_channel, &q.run_len);
+            RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, q, s));
+            if (e->cfg.kernel) {
+                e->h_spec.resize(spec_floats);
+                e->h_spec2.resize((size_t)N * 2);
+                RC_HIP(hipMemcpyAsync(e->h_spec.data(), e->d_spec.p, spec_floats * sizeof(float),
+                                      hipMemcpyDeviceToHost, s));
+                RC_HIP(hipStreamSynchronize(s));
+                for (int64_t w0 = 0; w0 < kc; w0 += hpw) {
+                    for (uint32_t c = 0; c < n_channels; ++c) {
+                        for (int64_t h = w0; h < std::min<int64_t>(w0 + hpw, kc); ++h) {
+                            float *sp = e->h_spec.data() + ((size_t)c * kc + h) * N * 2;
+                            // src/fft.rs:86-99: copy in, call apply(now_ms, bins), copy out
+                            const int krc = e->cfg.kernel(now_ms(e), sp, e->h_spec2.data(), N,
+                                                          e->cfg.kernel_user);
+                            if (krc == 0) memcpy(sp, e->h_spec2.data(), (size_t)N * 2 * sizeof(float));
+                            // non-zero == panic: keep the unmodified spectrum (src/fft.rs:100-106)
+                        }
+                    }
                 }
+                RC_HIP(hipMemcpyAsync(e->d_spec.p, e->h_spec.data(), spec_floats * sizeof(float),
+                                      hipMemcpyHostToDevice, s));
             }
+            RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, q, s));
+            launches += 2;
         }
-        RC_HIP(hipMemcpyAsync(e->d_spec.p, e->h_spec.data(), spec_floats * sizeof(float),
-                              hipMemcpyHostToDevice, s));
-        RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, p, s));
         rc::OlaParams o{};
         o.ybuf = (const float *)e->d_ybuf.p;
         o.tail = (float *)e->d_tail.p + (size_t)ch_first * H;
@@ -445,13 +406,33 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         o.out_origin = out_origin;
         o.env = e->d_env;
         o.amp = e->par.corrected_amp_factor;
-        o.pitch = (uint32_t)e->cfg.pitch_multiple;
+        o.pitch = e->cfg.pitch_multiple;
+        o.samples_needed = (uint32_t)e->par.samples_needed_per_window;
+        o.window_out_len = e->par.window_out_len;
         o.n_channels = n_channels;
         o.hop_first = k0;
         o.hop_count = kc;
         o.log2n = (uint32_t)e->log2n;
-        RC_HIP(rc::launch_ola(o, s));
-        RC_HIP(hipStreamSynchronize(s));
+        RC_HIP(rc::launch_ola(o, s, tail_only));
+        launches += 2;
+        if (e->cfg.kernel) RC_HIP(hipStreamSynchronize(s));  // h_spec is reused by the next chunk
+        return RC_OK;
+    };
+    if (timed) RC_HIP(hipEventRecord(e->ev0, s));
+    if (hop_first == 0)  // a fresh stream starts from H zeros (src/stretcher.rs:58-59)
+        RC_HIP(hipMemsetAsync((float *)e->d_tail.p + (size_t)ch_first * H, 0,
+                              (size_t)n_channels * H * sizeof(float), s));
+    else if (!e->cfg.kernel && (rc = run_chunk(hop_first - 1, 1, true)))
+        return rc;
+    for (int64_t k0 = hop_first; k0 < hop_first + hop_count; k0 += chunk_max) {
+        const int64_t kc = std::min<int64_t>(chunk_max, hop_first + hop_count - k0);
+        if ((rc = run_chunk(k0, kc, false))) return rc;
+    }
+    if (timed) {
+        RC_HIP(hipEventRecord(e->ev1, s));
+        e->stats_valid = true;
+        e->stats_hops = (uint64_t)hop_count * n_channels;
+        e->stats_launches = launches;
     }
     return RC_OK;
 }

@@ -50,7 +50,9 @@ struct OlaParams {
     int64_t out_origin;
     const float *env;
     float amp;
-    uint32_t pitch;
+    int32_t pitch;            // pitch_multiple: >= 1 decimates, <= -2 interpolates (one hop per window)
+    uint32_t samples_needed;  // samples_needed_per_window (pitch < 0)
+    uint32_t window_out_len;  // samples per next_window() (pitch < 0)
     uint32_t n_channels;
     int64_t hop_first;
     int64_t hop_count;

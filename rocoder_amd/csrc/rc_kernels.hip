@@ -869,11 +869,25 @@ __global__ __launch_bounds__(256) void ola_kernel(const OlaParams p) {
     const float *prev = hop_local > 0 ? yk - N + H : p.tail + (size_t)ch * H;
     float *outc = p.out + (size_t)ch * p.out_stride;
     const int64_t g0 = k * (int64_t)H;
-    for (uint32_t i = threadIdx.x; i < H; i += blockDim.x) {
-        const int64_t g = g0 + i;
-        if (p.pitch == 1 || g % p.pitch == 0) {
-            const float o = (yk[i] + prev[i]) * p.env[i] * p.amp;
-            outc[g / p.pitch - p.out_origin] = o;
+    if (p.pitch >= 1) {
+        for (uint32_t i = threadIdx.x; i < H; i += blockDim.x) {
+            const int64_t g = g0 + i;
+            if (p.pitch == 1 || g % p.pitch == 0) {
+                const float o = (yk[i] + prev[i]) * p.env[i] * p.amp;
+                outc[g / p.pitch - p.out_origin] = o;
+            }
+        }
+    } else {
+        // pitch <= -2: one hop per window; resample_slower (src/resampler.rs:20-35) emits
+        // (S-1)*f samples lerp(O[i], O[i+1], j/f) from the first S overlap-added samples
+        // (src/stretcher.rs:108-111; the rest of the half window is dropped as in the reference)
+        const uint32_t f = (uint32_t)(-p.pitch), S = p.samples_needed;
+        float *dst = outc + (k * (int64_t)p.window_out_len - p.out_origin);
+        for (uint32_t m = threadIdx.x; m < (S - 1) * f; m += blockDim.x) {
+            const uint32_t i = m / f, j = m - i * f;
+            const float cur = (yk[i] + prev[i]) * p.env[i] * p.amp;
+            const float nxt = (yk[i + 1] + prev[i + 1]) * p.env[i + 1] * p.amp;
+            dst[m] = cur + (nxt - cur) * ((float)j / (float)f);  // math::lerp, src/math.rs:28-30
         }
     }
 }

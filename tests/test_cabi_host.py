@@ -57,7 +57,7 @@ def test_invalid_parameters_rejected(bad):
 @pytest.mark.parametrize("L,N,f,p", [(26460000, 16384, 8.0, 1), (26460000, 16384, 8.0, 3),
                                      (2646000, 16384, 1.0, 1), (5292000, 65536, 32.0, 1),
                                      (0, 256, 1.0, 1), (100, 256, 4.0, 1), (256, 256, 1.0, 1),
-                                     (3001, 256, 8.0, 3)])
+                                     (3001, 256, 8.0, 3), (3000, 256, 1.5, -2), (20000, 1024, 4.0, -3)])
 def test_offline_output_len_matches_oracle(L, N, f, p):
     assert offline_output_len(L, window_len=N, factor=f, pitch_multiple=p) == \
         oc.offline_output_len(L, N, f, p)

@@ -47,14 +47,14 @@ def test_goldens_end_to_end(goldens):
     z, meta = goldens
     ran = 0
     for name, m in meta.items():
-        if "factor" not in m or m["pitch"] < 1:
-            continue  # negative pitch multiples are not on the GPU path yet (RC_EUNSUPPORTED)
+        if "factor" not in m:
+            continue
         x, y = z[name + "/x"], z[name + "/y"]
         got = ra.stretch(x, window_len=m["N"], factor=m["factor"], amplitude=m["amplitude"],
                          pitch_multiple=m["pitch"], seed=m["seed"], kernel=_kernel_for(m["kernel_gain"]))
         assert_parity(got, y, name)
         ran += 1
-    assert ran >= 6
+    assert ran >= 8
 
 
 def test_one_hop_golden(goldens):  # ReFFT seam: src/fft.rs:42-74
@@ -126,6 +126,38 @@ def test_large_window_streaming_equals_offline():
         wins.append(s.next_window().copy())
     ref = oc.stretch_offline(x[None], 65536, 16.0, 1.0, 1, seed=8)[0]
     assert_parity(np.concatenate(wins), ref, "N=65536 streaming")
+
+
+@pytest.mark.parametrize("N,L,f,p,ch", [(256, 3000, 1.5, -2, 1), (1024, 20000, 4.0, -3, 2),
+                                        (16384, 120000, 8.0, -2, 2), (4096, 30000, 4.0, -5, 1),
+                                        (32768, 150000, 6.0, -2, 1)])
+def test_negative_pitch_multiples_match_oracle(N, L, f, p, ch):
+    """Subharmonic shifts: resample_slower (src/resampler.rs:20-35), (S-1)*|p| samples per window
+    (src/stretcher.rs:47-51,108-113), including the reference's sample dropping for |p| >= 3."""
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, L) for c in range(ch)])
+    got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=0x5EED)
+    ref = oc.stretch_offline(x, N, f, 1.0, p, seed=0x5EED)
+    for c in range(ch):
+        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}")
+
+
+def test_negative_pitch_with_kernel_and_streaming():
+    ra = _engine_mod()
+    x = onp.synth_input(0, 40000)
+    w = oc.hanning(2048)
+    k = _kernel_for(0.5)
+    q: "queue.Queue" = queue.Queue()
+    s = ra.Stretcher(ra.AudioSpec(1, 44100), q, 3.0, 1.0, -2, w, seed=2, frequency_kernel=k)
+    for i in range(0, x.size, 9999):
+        q.put(x[i:i + 9999])
+    q.put(None)
+    wins = []
+    while not s.is_done():
+        wins.append(s.next_window().copy())
+    assert all(wn.size == 2046 for wn in wins)  # (S-1)*|p| = (1024-1)*2
+    ref = oc.stretch_offline(x[None], 2048, 3.0, 1.0, -2, seed=2, kernel=k)[0]
+    assert_parity(np.concatenate(wins), ref, "p=-2 kernel streaming")
 
 
 def test_zero_input_gives_zero_output():
@@ -435,6 +467,6 @@ def test_unsupported_configs_fail_loudly():
     with pytest.raises(_lib.RocoderError) as ei:
         ra.stretch(np.zeros((1, 5000), np.float32), window_len=1000)
     assert ei.value.code == _lib.RC_EUNSUPPORTED
-    with pytest.raises(_lib.RocoderError) as ei:
-        ra.stretch(np.zeros((1, 5000), np.float32), window_len=1024, pitch_multiple=-2)
+    with pytest.raises(_lib.RocoderError) as ei:  # user kernels on the large-window path: not yet
+        ra.stretch(np.zeros((1, 70000), np.float32), window_len=32768, kernel=lambda t, s: s)
     assert ei.value.code == _lib.RC_EUNSUPPORTED
