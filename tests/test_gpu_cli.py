@@ -1,0 +1,104 @@
+"""GPU tests of the C++ CLI twin (`rocoder -i in.wav -o out.wav ...`): WAV in -> engine -> f32 WAV
+out, compared with the oracle run on the samples the reference's reader would decode."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rms
+from oracle import cbind as oc
+from oracle import oracle_np as onp
+from wavutil import read_wav_f32, write_wav
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ROOT, "rocoder_amd", "bin", "rocoder")
+TOL = 1e-4
+
+
+def run(*args, **kw):
+    r = subprocess.run([CLI, *args], capture_output=True, text=True, timeout=300, **kw)
+    assert r.returncode == 0, r.stderr
+    return r
+
+
+def check(got, ref):
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    for c in range(ref.shape[0]):
+        e, r = rms(got[c].astype(np.float64) - ref[c]), rms(ref[c])
+        assert e <= TOL and e <= TOL * r + 1e-9, (c, e, r)
+
+
+@pytest.mark.parametrize("fmt,extra,okw", [
+    ("i16", ["-w", "1024", "-f", "4"], dict(window_len=1024, factor=4.0)),
+    ("f32", ["-w", "4096", "-f", "8", "-p", "2", "-a", "0.5"],
+     dict(window_len=4096, factor=8.0, pitch_multiple=2, amplitude=0.5)),
+    ("i24", ["--window", "2048", "--factor", "2", "--pitch_multiple", "-2"],
+     dict(window_len=2048, factor=2.0, pitch_multiple=-2)),
+])
+def test_cli_matches_oracle(tmp_path, fmt, extra, okw):
+    x = np.stack([onp.synth_input(c, 30000) for c in range(2)])
+    wav, out = str(tmp_path / "in.wav"), str(tmp_path / "out.wav")
+    dec = write_wav(wav, x, 44100, fmt)
+    run("-i", wav, "-o", out, "--seed", "77", *extra)
+    rate, got = read_wav_f32(out)
+    assert rate == 44100
+    check(got, oc.stretch_offline(dec, seed=77, **okw))
+
+
+def test_cli_default_window_start_duration_rotate(tmp_path):
+    x = np.stack([onp.synth_input(c, 44100 * 3) for c in range(2)])
+    wav, out = str(tmp_path / "in.wav"), str(tmp_path / "out.wav")
+    dec = write_wav(wav, x, 44100, "i16")
+    run("-i", wav, "-o", out, "-f", "2", "-s", "0:0:0.5", "-d", "2", "--rotate-channels", "--seed", "3")
+    _, got = read_wav_f32(out)
+    clip = dec[:, 22050:22050 + 88200][::-1]  # clip (audio.rs:57-63) then rotate_right(1) (:73-75)
+    check(got, oc.stretch_offline(clip, 16384, 2.0, 1.0, 1, seed=3))
+
+
+def test_cli_stdin_input(tmp_path):
+    x = onp.synth_input(0, 20000)[None]
+    wav, out = str(tmp_path / "in.wav"), str(tmp_path / "out.wav")
+    dec = write_wav(wav, x, 48000, "i32")
+    with open(wav, "rb") as f:
+        r = subprocess.run([CLI, "-i", "-", "-o", out, "-w", "512", "-f", "3", "--seed", "1"], stdin=f,
+                           capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rate, got = read_wav_f32(out)
+    assert rate == 48000
+    check(got, oc.stretch_offline(dec, 512, 3.0, 1.0, 1, seed=1, sample_rate=48000))
+
+
+KERNEL_C = r"""
+#include <stddef.h>
+#include <stdint.h>
+/* the README's example kernel (README.md:121-128) in its C-ABI form: multiply every bin by 2 */
+int apply(uint64_t time_ms, const float *in, float *out, size_t n, void *user) {
+    (void)time_ms; (void)user;
+    for (size_t i = 0; i < 2 * n; ++i) out[i] = in[i] * 2.0f;
+    return 0;
+}
+"""
+
+
+def test_cli_freq_kernel_compiled_from_source(tmp_path):
+    x = np.stack([onp.synth_input(c, 20000) for c in range(2)])
+    wav, out, ksrc = str(tmp_path / "in.wav"), str(tmp_path / "out.wav"), str(tmp_path / "kernel.c")
+    open(ksrc, "w").write(KERNEL_C)
+    dec = write_wav(wav, x, 44100, "f32")
+    r = run("-i", wav, "-o", out, "-w", "2048", "-f", "4", "--freq-kernel", ksrc, "--seed", "9")
+    assert "Got new kernel" in r.stderr  # src/fft.rs:79
+    _, got = read_wav_f32(out)
+    ref = oc.stretch_offline(dec, 2048, 4.0, 1.0, 1, seed=9, kernel=lambda t, s: s * np.float32(2.0))
+    check(got, ref)
+
+
+def test_cli_broken_kernel_source_falls_back_to_noop(tmp_path):
+    x = onp.synth_input(0, 10000)[None]
+    wav, out, ksrc = str(tmp_path / "in.wav"), str(tmp_path / "out.wav"), str(tmp_path / "kernel.c")
+    open(ksrc, "w").write("this is not C")
+    dec = write_wav(wav, x, 44100, "f32")
+    r = run("-i", wav, "-o", out, "-w", "1024", "-f", "2", "--freq-kernel", ksrc, "--seed", "9")
+    assert "Failed to compile library" in r.stderr  # src/hotswapper.rs:39
+    _, got = read_wav_f32(out)
+    check(got, oc.stretch_offline(dec, 1024, 2.0, 1.0, 1, seed=9))
