@@ -103,6 +103,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Exactly ONE line on stdout (the JSON): RCCL / the HIP runtime print banners to fd 1, so park
+    # the real stdout and point fd 1 at stderr until the result is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,9 +119,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: RCCL barrier/all-reduce
         import torch.distributed as dist
 
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -205,7 +212,7 @@ def main():
             cb = cpu_baseline()
             res["cpu_baseline"] = cb
             res["config"]["x_cpu"] = round(value / cb["value"], 1)
-        print(json.dumps(res), flush=True)
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
