@@ -859,6 +859,400 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
     }
 }
 
+
+// uniform pointer to sample k*step of the hop's input, forced into SGPRs. Hops whose window runs
+// past the end of the closed input read the engine's zero-padded tail copy (stretcher.rs:129-132).
+__device__ __forceinline__ GF hop_src(const HopParams &p, GF xc, GF xt, int64_t k) {
+    const int64_t off = (k >= p.tail_hop_first) ? (k * (int64_t)p.step - p.tail_origin)
+                                                : (k * (int64_t)p.step - p.in_origin);
+    const unsigned long long sa =
+        (unsigned long long)((k >= p.tail_hop_first) ? xt : xc) + (unsigned long long)off * 4ull;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sa);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(sa >> 32));
+    return (GF)(((unsigned long long)hi << 32) | lo);
+}
+
+// =============================== v2 fused kernel (N = 16384) =================================
+// Same math as hop_kernel<.., MODE_FUSED>, restructured so that (tools/proto_v2.py is the index
+// model):
+//   * BOTH transforms are DIT (3 packed FMAs per butterfly). The forward transform's bit-reversed
+//     input order costs nothing: it is the order in which the thread's registers are loaded.
+//   * the last forward pass leaves thread t with the natural-order bins of residues r = t and
+//     512 - t (mod 512), i.e. every (j, M - j) pair sits in one thread: the real split, |X|, the
+//     four phasors and the Hermitian fold run in registers, and the first inverse pass (position
+//     bits 0..3 = frequency bits 9..12) follows without touching LDS. Residues 0 and 256 pair
+//     with themselves; thread 0 owns them and hands its 17 pairs to lanes 0..16 of wave 0 through
+//     a 32-element LDS scratch.
+//   * 4 LDS exchanges per hop instead of 6 + the middle-stage round trip. Index maps
+//     f1(n) = n + (n >> 5) and f3(n) = n + (n >> 5) + (n >> 8) keep every access pattern at most
+//     2-way conflicted on a few lanes; both are additive over disjoint bit fields, so each access is
+//     a per-thread base VGPR + an immediate offset.
+#ifndef RC_V2
+#define RC_V2 1
+#endif
+#ifndef RC_PRIO
+#define RC_PRIO 0
+#endif
+#ifndef RC_LDS_PAD
+#define RC_LDS_PAD 0  // diagnostic: extra dynamic LDS to force one workgroup per CU
+#endif
+constexpr int f1_idx(int n) { return n + (n >> 5); }
+constexpr int f3_idx(int n) { return n + (n >> 5) + (n >> 8); }
+constexpr int brev_c(int x, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; ++b) r |= ((x >> b) & 1) << (bits - 1 - b);
+    return r;
+}
+
+// full DIT butterfly in one asm statement (one boundary pad instead of three):
+//   r = a + w b (or a + conj(w) b),  o = 2a - r
+template <bool CONJ>
+__device__ __forceinline__ void pk_dit(v2f a, v2f b, v2f w, v2f &r, v2f &o) {
+    v2f t;
+    const v2f two = {2.0f, 2.0f};
+    if (CONJ)
+        asm("v_pk_fma_f32 %2, %3, %4, %5 op_sel_hi:[1,0,1]\n\t"
+            "v_pk_fma_f32 %0, %3, %4, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+            "v_pk_fma_f32 %1, %5, %6, %0 neg_lo:[0,0,1] neg_hi:[0,0,1]"
+            : "=&v"(r), "=&v"(o), "=&v"(t) : "v"(b), "v"(w), "v"(a), "s"(two));
+    else
+        asm("v_pk_fma_f32 %2, %3, %4, %5 op_sel_hi:[1,0,1]\n\t"
+            "v_pk_fma_f32 %0, %3, %4, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+            "v_pk_fma_f32 %1, %5, %6, %0 neg_lo:[0,0,1] neg_hi:[0,0,1]"
+            : "=&v"(r), "=&v"(o), "=&v"(t) : "v"(b), "v"(w), "v"(a), "s"(two));
+}
+// same with a compile-time twiddle held in SGPRs
+template <bool CONJ>
+__device__ __forceinline__ void pk_dit_k(v2f a, v2f b, v2f k, v2f &r, v2f &o) {
+    v2f t;
+    const v2f two = {2.0f, 2.0f};
+    if (CONJ)
+        asm("v_pk_fma_f32 %2, %3, %4, %5 op_sel_hi:[1,0,1]\n\t"
+            "v_pk_fma_f32 %0, %3, %4, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
+            "v_pk_fma_f32 %1, %5, %6, %0 neg_lo:[0,0,1] neg_hi:[0,0,1]"
+            : "=&v"(r), "=&v"(o), "=&v"(t) : "v"(b), "s"(k), "v"(a), "s"(two));
+    else
+        asm("v_pk_fma_f32 %2, %3, %4, %5 op_sel_hi:[1,0,1]\n\t"
+            "v_pk_fma_f32 %0, %3, %4, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
+            "v_pk_fma_f32 %1, %5, %6, %0 neg_lo:[0,0,1] neg_hi:[0,0,1]"
+            : "=&v"(r), "=&v"(o), "=&v"(t) : "v"(b), "s"(k), "v"(a), "s"(two));
+}
+// base * k in one statement
+__device__ __forceinline__ v2f pk_cmul_k1(v2f a, v2f k) {
+    v2f t, r;
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(r), "=&v"(t) : "v"(a), "s"(k));
+    return r;
+}
+
+// ---- asm-free packed butterflies: plain vector code, hipcc picks the op_sel / neg / inline-constant
+// forms itself (no inline-asm boundary pads, free scheduling).
+//   DIT: r = a + w b = fma(b.yx, w2, fma(b, w.xx, a)),  w2 = (-w.y, w.y)   [conj: w2 = (w.y, -w.y)]
+//        o = a - w b = 2a - r
+__device__ __forceinline__ void vdit(v2f a, v2f b, v2f w, v2f w2, v2f &r, v2f &o) {
+    const v2f t = __builtin_elementwise_fma(b, __builtin_shufflevector(w, w, 0, 0), a);
+    r = __builtin_elementwise_fma(__builtin_shufflevector(b, b, 1, 0), w2, t);
+    const v2f two = {2.0f, 2.0f};
+    o = __builtin_elementwise_fma(a, two, -r);
+}
+__device__ __forceinline__ v2f vcmul(v2f a, v2f k) {  // a * k
+    const v2f t = __builtin_shufflevector(a, a, 0, 0) * k;
+    return __builtin_elementwise_fma(__builtin_shufflevector(a, a, 1, 1), v2f{-k.y, k.x}, t);
+}
+
+// DIT stages S_LO..S_HI on NREG registers: register bit (s - REG_LO) <-> position bit s; the
+// position bits below REG_LO are the runtime value l (< 2^REG_LO; HAS_L = false means l == 0).
+//   a' = a + w b, b' = a - w b, w = exp(-2 pi i (p mod 2^s) / 2^(s+1))   (conjugated when CONJ)
+template <int NREG, int M_LOG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L>
+__device__ __forceinline__ void dit_stages(v2f (&v)[NREG], int l, GV2 wtab) {
+    const v2f sgn = CONJ ? v2f{1.0f, -1.0f} : v2f{-1.0f, 1.0f};
+#pragma unroll
+    for (int s = S_LO; s <= S_HI; ++s) {
+        const int rb = s - REG_LO;
+        const int half = 1 << rb;
+        v2f base = {1.f, 0.f};
+        if (HAS_L) {
+            float2 bt = ldg2(wtab + (l << (M_LOG - 1 - s)));  // W_{2^(s+1)}^l
+            opaque(bt);
+            base = to_v(bt);
+        }
+#pragma unroll
+        for (int q0 = 0; q0 < NREG; ++q0) {
+            if (q0 & half) continue;
+            const int q1 = q0 | half;
+            const int c = q0 & (half - 1);
+            const int kidx = c * (16 >> rb);  // exp(-2 pi i c / 2^(rb+1)) = W32^kidx
+            const v2f a = v[q0], b = v[q1];
+            const v2f kc = {W32_RE[kidx & 15], W32_IM[kidx & 15]};
+            if (!HAS_L && c == 0) {
+                v[q0] = a + b;
+                v[q1] = a - b;
+            } else if (!HAS_L && kidx == 8) {  // w = -i (forward) / +i (inverse): w b = -+ i b
+                const v2f ib = __builtin_shufflevector(b, b, 1, 0) * sgn;  // conj: -i b... see below
+                // forward: w b = -i b = (b.y, -b.x) = b.yx * (1, -1) = -(b.yx * sgn_fwd)
+                // inverse: conj(w) b = +i b = (-b.y, b.x) = b.yx * (-1, 1) = -(b.yx * sgn_inv)
+                v[q0] = a - ib;
+                v[q1] = a + ib;
+            } else if (!HAS_L) {
+                const v2f w2 = v2f{kc.y, kc.y} * sgn;
+                vdit(a, b, kc, w2, v[q0], v[q1]);
+            } else {
+                v2f w;
+                if (c == 0) w = base;
+                else if (kidx == 8) w = v2f{base.y, -base.x};
+                else w = vcmul(base, kc);
+                const v2f w2 = __builtin_shufflevector(w, w, 1, 1) * sgn;
+                vdit(a, b, w, w2, v[q0], v[q1]);
+            }
+        }
+    }
+}
+
+// one (ja, M - ja) pair entirely in registers; x1 = ja * mul + k0 (phase counter of bin ja)
+template <int LOG2N>
+__device__ __forceinline__ void pair_regs(float2 A, float2 Bp, float2 w, uint32_t x1, PhaseKey key,
+                                          float2 &VA, float2 &VB, bool dc = false) {
+    constexpr uint32_t N = 1u << LOG2N, M = N / 2;
+    const uint32_t cN = N * key.mul + 2u * key.k0, cM = M * key.mul + 2u * key.k0, cP = M * key.mul;
+    const float nkappa = -0.25f / (float)N;
+    float2 X1, X2c;
+    pair_analyze(A, Bp, w, X1, X2c);
+    const float m1 = cabs_fast(X1) * nkappa, m2 = cabs_fast(X2c) * nkappa;
+    float c1, s1, c2, s2, c3, s3, c4, s4;
+    phase_ncs_x(x1, c1, s1);
+    phase_ncs_x(dc ? x1 : cN - x1, c2, s2);  // bin N - ja; ja == 0 wraps onto bin 0 itself
+    phase_ncs_x(cM - x1, c3, s3);
+    phase_ncs_x(cP + x1, c4, s4);
+    const float px = m1 * (c1 + c2), py = m1 * (s1 - s2);
+    const float qx = m2 * (c3 + c4), qy = m2 * (s4 - s3);
+    const float sx = px + qx, sy = py + qy, rx = px - qx, ry = py - qy;
+    const float ux = rx * w.x + ry * w.y, uy = ry * w.x - rx * w.y;
+    VA = make_float2(sx - uy, sy + ux);
+    VB = make_float2(sx + uy, ux - sy);
+}
+
+template <bool PITCH1>
+__global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
+    constexpr int LOG2N = 14, m = 13, M = 1 << m, H = M, T = 256, P = 32, PH = 16;
+    constexpr int RES = 512;                      // residues of the last forward pass
+    constexpr int SCR = f3_idx(M) + 8;            // 32-element scratch for thread 0's pairs
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int tid = threadIdx.x;
+    const uint32_t run = blockIdx.x % p.runs_per_channel;
+    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
+    int64_t k_end = k_begin + p.run_len;
+    if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
+    if (k_begin >= k_end) return;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
+    const unsigned lane2 = 2u * (unsigned)tid;
+    GV2 wtab = (GV2)p.wtab;
+    const uint32_t pitch = PITCH1 ? 1u : p.pitch;
+
+    // residues of this thread and per-thread LDS bases (thread part of every access pattern)
+    const int r = tid, rb = tid ? RES - tid : RES / 2;
+    const int l4 = tid & 15, uu = tid >> 4;
+    const int pos4 = (uu << 9) | l4;                                  // LOR = 4 layout, q = 0
+    const int bE1s = f3_idx((int)(__brev((unsigned)tid) >> 24) << 5);  // brev8(t) << 5
+    const int b4f3 = f3_idx(pos4), b4f1 = f1_idx(pos4);
+    const int bAr = f1_idx(r), bBr = f1_idx(rb);
+    const int bE3a = f3_idx((int)(__brev((unsigned)r) >> 23) << 4);    // brev9(r) << 4
+    const int bE3b = f3_idx((int)(__brev((unsigned)rb) >> 23) << 4);
+    const int bE4l = f1_idx(tid);
+
+    float2 tail[PH];
+#pragma unroll
+    for (int q = 0; q < PH; ++q) tail[q] = make_float2(0.f, 0.f);
+#if RC_PRIO
+    // the two workgroups of a CU run the same code; a static priority split keeps them from
+    // marching in lockstep (one computes while the other waits on LDS / memory)
+    if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(RC_PRIO);
+#endif
+
+    for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
+        const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+        v2f v[P];
+        {   // load in F1 order: register q holds z[brev5(q) * T + t] * window
+            GF src = hop_src(p, xc, xt, k);
+            GF win = per_hop(p.window);
+            float xr0[P], xr1[P], wr0[P], wr1[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                xr0[q] = (src + 2 * T * q)[lane2];
+                xr1[q] = (src + 2 * T * q)[lane2 + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                wr0[q] = (win + 2 * T * q)[lane2];
+                wr1[q] = (win + 2 * T * q)[lane2 + 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                v[brev_c(q, 5)].x = xr0[q] * wr0[q];
+                v[brev_c(q, 5)].y = xr1[q] * wr1[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- forward: F1 (bits 0..4, constants), E1, F2 (bits 5..8), E2, F3 (bits 9..12)
+        dit_stages<32, m, 0, 4, 0, false, false>(v, 0, wtab);
+#pragma unroll
+        for (int q = 0; q < P; ++q) lds[bE1s + f3_idx(q)] = to_f2(v[q]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < P; ++q) v[q] = to_v(lds[b4f3 + f3_idx(q << 4)]);
+        __syncthreads();
+        dit_stages<32, m, 5, 8, 4, false, true>(v, l4, wtab);
+#pragma unroll
+        for (int q = 0; q < P; ++q) lds[b4f1 + f1_idx(q << 4)] = to_f2(v[q]);
+        __syncthreads();
+        v2f va[16], vb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            va[q] = to_v(lds[bAr + f1_idx(RES * q)]);
+            vb[q] = to_v(lds[bBr + f1_idx(RES * q)]);
+        }
+        __syncthreads();
+        dit_stages<16, m, 9, 12, 9, false, true>(va, r, wtab);
+        dit_stages<16, m, 9, 12, 9, false, true>(vb, rb, wtab);
+
+        // ---- middle stage in registers: pair (A[q], B[15-q]) = bins (r + 512 q, M - that)
+        if (tid == 0) {  // thread 0 owns the self-paired residues 0 and 256: hand them to wave 0
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                lds[SCR + q] = to_f2(va[q]);
+                lds[SCR + 16 + q] = to_f2(vb[q]);
+            }
+        }
+        {
+            int rr = r;
+            opaque(rr);
+            const float2 wr = ldg2((GV2)p.rtab + rr);          // exp(-2 pi i r / N), r < 512
+            const uint32_t x0 = (uint32_t)rr * key.mul + key.k0;  // counter of bin r
+            const uint32_t dx = (uint32_t)RES * key.mul;          // + 512 bins
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                // exp(-2 pi i (r + 512 q) / N) = wr * W32^q
+                const float2 wq = q == 0 ? wr : (q == 8 ? make_float2(wr.y, -wr.x)
+                                  : cmul(wr, make_float2(W32_RE[q & 15], W32_IM[q & 15])));
+                float2 VA, VB;
+                pair_regs<LOG2N>(to_f2(va[q]), to_f2(vb[15 - q]), wq, x0 + (uint32_t)q * dx, key, VA, VB);
+                va[q] = to_v(VA);
+                vb[15 - q] = to_v(VB);
+            }
+        }
+        if (tid < 64) {  // wave 0: lanes 0..16 compute thread 0's 17 pairs from the scratch
+            const int i = tid;
+            if (i <= 16) {
+                int ja, ia, ib;
+                if (i == 0) { ja = 0; ia = 0; ib = 0; }
+                else if (i <= 7) { ja = RES * i; ia = i; ib = 16 - i; }
+                else if (i == 8) { ja = RES * 8; ia = 8; ib = 8; }
+                else { ja = RES / 2 + RES * (i - 9); ia = 16 + (i - 9); ib = 16 + 15 - (i - 9); }
+                const float2 A = lds[SCR + ia], Bp = lds[SCR + ib];
+                const float2 w = ldg2(wtab + (ja >> 1));  // exp(-2 pi i ja / N) = W_M^(ja/2), ja even
+                float2 VA, VB;
+                pair_regs<LOG2N>(A, Bp, w, (uint32_t)ja * key.mul + key.k0, key, VA, VB, ja == 0);
+                lds[SCR + ia] = VA;
+                if (ib != ia) lds[SCR + ib] = VB;
+            }
+            if (tid == 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    va[q] = to_v(lds[SCR + q]);
+                    vb[q] = to_v(lds[SCR + 16 + q]);
+                }
+            }
+        }
+        // ---- inverse: I1 in registers (position bits 0..3 = brev4 of the register index)
+        v2f pa[16], pb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            pa[brev_c(q, 4)] = va[q];
+            pb[brev_c(q, 4)] = vb[q];
+        }
+        dit_stages<16, m, 0, 3, 0, true, false>(pa, 0, wtab);
+        dit_stages<16, m, 0, 3, 0, true, false>(pb, 0, wtab);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            lds[bE3a + f3_idx(q)] = to_f2(pa[q]);
+            lds[bE3b + f3_idx(q)] = to_f2(pb[q]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < P; ++q) v[q] = to_v(lds[b4f3 + f3_idx(q << 4)]);
+        __syncthreads();
+        dit_stages<32, m, 4, 8, 4, true, true>(v, l4, wtab);
+#pragma unroll
+        for (int q = 0; q < P; ++q) lds[b4f1 + f1_idx(q << 4)] = to_f2(v[q]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < P; ++q) v[q] = to_v(lds[bE4l + f1_idx(q << 8)]);
+        __syncthreads();
+        dit_stages<32, m, 9, 12, 8, true, true>(v, tid, wtab);
+
+        // ---- epilogue: synthesis window, overlap-add with the carried tail, store
+        {
+            GF wsrc = per_hop(p.window);
+            float wr0[P], wr1[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                wr0[q] = (wsrc + 2 * T * q)[lane2];
+                wr1[q] = (wsrc + 2 * T * q)[lane2 + 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                v[q].x *= wr0[q];
+                v[q].y *= wr1[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (k >= k_begin) {
+            const int64_t g0 = k * (int64_t)H;
+            GF esrc = per_hop(p.env);
+            if constexpr (PITCH1) {
+                GFW dst = outc + (g0 - p.out_origin);
+                float er0[PH], er1[PH];
+#pragma unroll
+                for (int q = 0; q < PH; ++q) {
+                    er0[q] = (esrc + 2 * T * q)[lane2];
+                    er1[q] = (esrc + 2 * T * q)[lane2 + 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < PH; ++q) {
+                    float2 o;  // stretcher.rs:97-100 operation order
+                    o.x = (v[q].x + tail[q].x) * er0[q] * p.amp;
+                    o.y = (v[q].y + tail[q].y) * er1[q] * p.amp;
+                    stg2((GV2W)(dst + 2 * T * q + lane2), o);
+                }
+            } else {
+                const int64_t kq = g0 / pitch;
+                const uint32_t kr = (uint32_t)(g0 % pitch);
+                GFW dst = outc + (kq - p.out_origin);
+                int t2 = tid;
+                opaque(t2);
+#pragma unroll
+                for (int q = 0; q < PH; ++q) {
+                    const uint32_t i0 = 2u * (uint32_t)(t2 + T * q);
+                    const float o0 = (v[q].x + tail[q].x) * (esrc + 2 * T * q)[lane2] * p.amp;
+                    const float o1 = (v[q].y + tail[q].y) * (esrc + 2 * T * q)[lane2 + 1] * p.amp;
+                    const uint32_t a0 = kr + i0, a1 = a0 + 1;
+                    const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
+                    if (d0 * pitch == a0) dst[d0] = o0;
+                    if (d1 * pitch == a1) dst[d1] = o1;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PH; ++q) tail[q] = to_f2(v[q + PH]);
+    }
+}
+
 // Overlap-add for the user-kernel path (gather form, two terms per output sample).
 __global__ __launch_bounds__(256) void ola_kernel(const OlaParams p) {
     const uint32_t N = 1u << p.log2n, H = N / 2;
@@ -907,7 +1301,11 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
     const size_t lds = sizeof(float2) * G::LDS_FLOAT2;
     switch (mode) {
         case MODE_FUSED:
-            if (p.pitch == 1)
+            if (RC_V2 && LOG2N == 14) {
+                const size_t lds2 = sizeof(float2) * (size_t)(f3_idx(G::M) + 8 + 32) + RC_LDS_PAD;
+                if (p.pitch == 1) hipLaunchKernelGGL((hop2_kernel<true>), grid, block, lds2, s, p);
+                else hipLaunchKernelGGL((hop2_kernel<false>), grid, block, lds2, s, p);
+            } else if (p.pitch == 1)
                 hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true>), grid, block, lds, s, p);
             else
                 hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, false>), grid, block, lds, s, p);

@@ -24,7 +24,7 @@ out = sys.argv[1]
 acc = collections.defaultdict(list)
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "hop_kernel" in r["Kernel_Name"]:
+        if "hop" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as g:
     for k in sorted(acc):
