@@ -108,10 +108,12 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-// ---- hand-packed complex arithmetic (v_pk_*_f32 with op_sel / neg modifiers, no shuffles) -------
+// ---- packed (re,im) arithmetic --------------------------------------------------------------
 // A lone wave issues one VALU op per ~4.6 cycles whether it is packed or not (profiles/
-// r01_ubench_instruction_rates.txt), so packing (re,im) halves the time a wave needs per butterfly
-// whenever its SIMD partner is waiting on LDS / memory.
+// r01_ubench_instruction_rates.txt), so v_pk_*_f32 on (re,im) pairs halves the time a wave needs per
+// butterfly whenever its SIMD partner is waiting on LDS / memory. The butterflies are written as
+// plain ext-vector code: hipcc selects v_pk_fma/mul/add with op_sel, neg and SGPR/inline constants
+// by itself, so there are no inline-asm boundary pads and the scheduler is free.
 #ifndef RC_PK
 #define RC_PK 1
 #endif
@@ -122,62 +124,6 @@ __device__ __forceinline__ v2f to_v(float2 a) {
     return r;
 }
 __device__ __forceinline__ float2 to_f2(v2f a) { return make_float2(a.x, a.y); }
-// a * w (complex)
-__device__ __forceinline__ v2f pk_cmul(v2f a, v2f w) {
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=v"(r) : "v"(a), "v"(w), "v"(t));
-    return r;
-}
-// a * k, k a compile-time constant kept in an SGPR pair
-__device__ __forceinline__ v2f pk_cmul_k(v2f a, v2f k) {
-    v2f t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(k));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=v"(r) : "v"(a), "s"(k), "v"(t));
-    return r;
-}
-// a + conj(w) * b
-__device__ __forceinline__ v2f pk_cmla_conj(v2f a, v2f w, v2f b) {
-    v2f t, r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(b), "v"(w), "v"(a));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
-        : "=v"(r) : "v"(b), "v"(w), "v"(t));
-    return r;
-}
-__device__ __forceinline__ v2f pk_cmla_conj_k(v2f a, v2f k, v2f b) {
-    v2f t, r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "v"(b), "s"(k), "v"(a));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
-        : "=v"(r) : "v"(b), "s"(k), "v"(t));
-    return r;
-}
-// 2a - r
-__device__ __forceinline__ v2f pk_2a_minus(v2f a, v2f r) {
-    v2f o;
-    const v2f two = {2.0f, 2.0f};
-    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(o) : "v"(a), "s"(two), "v"(r));
-    return o;
-}
-// (a - b) * (-i) = (a.y - b.y, b.x - a.x)
-__device__ __forceinline__ v2f pk_sub_mul_mi(v2f a, v2f b) {
-    v2f o;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]"
-        : "=v"(o) : "v"(a), "v"(b));
-    return o;
-}
-// a + i b = (a.x - b.y, a.y + b.x) ; a - i b = (a.x + b.y, a.y - b.x)
-__device__ __forceinline__ v2f pk_add_ib(v2f a, v2f b) {
-    v2f o;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o) : "v"(a), "v"(b));
-    return o;
-}
-__device__ __forceinline__ v2f pk_sub_ib(v2f a, v2f b) {
-    v2f o;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b));
-    return o;
-}
 
 constexpr int pad_idx(int n) { return n + (n >> 5); }
 
@@ -279,41 +225,47 @@ __device__ __forceinline__ void run_pass(float2 (&v)[G::P], int tid,
             const int kidx = c * (16 >> r);
             const float2 a = v[q0], b = v[q1];
 #if RC_PK
+            // packed (re,im) arithmetic as plain vector code: hipcc emits v_pk_* with op_sel / neg /
+            // SGPR-constant operands itself (no inline-asm boundary pads)
             const v2f av = to_v(a), bv = to_v(b);
             const v2f kc = {W32_RE[kidx & 15], W32_IM[kidx & 15]};
+            const v2f two = {2.0f, 2.0f};
             if (LOR == 0 && c == 0) {  // w = 1
                 v[q0] = to_f2(av + bv);
                 v[q1] = to_f2(av - bv);
             } else if (LOR == 0 && kidx == 8) {  // w = -i
-                if (!INV) {
+                const v2f ibm = __builtin_shufflevector(bv, bv, 1, 0) * v2f{-1.0f, 1.0f};  // i b
+                if (!INV) {  // (a - b)(-i) = -i a + i b
+                    const v2f iam = __builtin_shufflevector(av, av, 1, 0) * v2f{-1.0f, 1.0f};
                     v[q0] = to_f2(av + bv);
-                    v[q1] = to_f2(pk_sub_mul_mi(av, bv));
-                } else {
-                    v[q0] = to_f2(pk_add_ib(av, bv));
-                    v[q1] = to_f2(pk_sub_ib(av, bv));
-                }
-            } else if (LOR == 0) {  // compile-time twiddle in an SGPR pair
-                if (!INV) {
-                    v[q0] = to_f2(av + bv);
-                    v[q1] = to_f2(pk_cmul_k(av - bv, kc));
-                } else {
-                    const v2f rv = pk_cmla_conj_k(av, kc, bv);
-                    v[q0] = to_f2(rv);
-                    v[q1] = to_f2(pk_2a_minus(av, rv));
+                    v[q1] = to_f2(ibm - iam);
+                } else {  // a +- i b
+                    v[q0] = to_f2(av + ibm);
+                    v[q1] = to_f2(av - ibm);
                 }
             } else {
                 v2f w;
-                const v2f bs = to_v(base);
-                if (c == 0) w = bs;
+                if (LOR == 0) w = kc;
+                else if (c == 0) w = to_v(base);
                 else if (kidx == 8) w = v2f{base.y, -base.x};
-                else w = pk_cmul_k(bs, kc);
-                if (!INV) {
+                else {
+                    const v2f bs = to_v(base);
+                    const v2f t0 = __builtin_shufflevector(bs, bs, 0, 0) * kc;
+                    w = __builtin_elementwise_fma(__builtin_shufflevector(bs, bs, 1, 1),
+                                                  v2f{-kc.y, kc.x}, t0);
+                }
+                if (!INV) {  // b' = (a - b) w = d.xx * w + d.yy * (-w.y, w.x)
+                    const v2f d = av - bv;
+                    const v2f wm = __builtin_shufflevector(w, w, 1, 0) * v2f{-1.0f, 1.0f};
+                    const v2f t0 = __builtin_shufflevector(d, d, 0, 0) * w;
                     v[q0] = to_f2(av + bv);
-                    v[q1] = to_f2(pk_cmul(av - bv, w));
-                } else {
-                    const v2f rv = pk_cmla_conj(av, w, bv);
+                    v[q1] = to_f2(__builtin_elementwise_fma(__builtin_shufflevector(d, d, 1, 1), wm, t0));
+                } else {  // a' = a + conj(w) b, b' = 2a - a'
+                    const v2f w2 = __builtin_shufflevector(w, w, 1, 1) * v2f{1.0f, -1.0f};
+                    const v2f t0 = __builtin_elementwise_fma(bv, __builtin_shufflevector(w, w, 0, 0), av);
+                    const v2f rv = __builtin_elementwise_fma(__builtin_shufflevector(bv, bv, 1, 0), w2, t0);
                     v[q0] = to_f2(rv);
-                    v[q1] = to_f2(pk_2a_minus(av, rv));
+                    v[q1] = to_f2(__builtin_elementwise_fma(av, two, -rv));
                 }
             }
 #else
@@ -901,48 +853,6 @@ constexpr int f3_idx(int n) { return n + (n >> 5) + (n >> 8); }
 constexpr int brev_c(int x, int bits) {
     int r = 0;
     for (int b = 0; b < bits; ++b) r |= ((x >> b) & 1) << (bits - 1 - b);
-    return r;
-}
-
-// full DIT butterfly in one asm statement (one boundary pad instead of three):
-//   r = a + w b (or a + conj(w) b),  o = 2a - r
-template <bool CONJ>
-__device__ __forceinline__ void pk_dit(v2f a, v2f b, v2f w, v2f &r, v2f &o) {
-    v2f t;
-    const v2f two = {2.0f, 2.0f};
-    if (CONJ)
-        asm("v_pk_fma_f32 %2, %3, %4, %5 op_sel_hi:[1,0,1]\n\t"
-            "v_pk_fma_f32 %0, %3, %4, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
-            "v_pk_fma_f32 %1, %5, %6, %0 neg_lo:[0,0,1] neg_hi:[0,0,1]"
-            : "=&v"(r), "=&v"(o), "=&v"(t) : "v"(b), "v"(w), "v"(a), "s"(two));
-    else
-        asm("v_pk_fma_f32 %2, %3, %4, %5 op_sel_hi:[1,0,1]\n\t"
-            "v_pk_fma_f32 %0, %3, %4, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
-            "v_pk_fma_f32 %1, %5, %6, %0 neg_lo:[0,0,1] neg_hi:[0,0,1]"
-            : "=&v"(r), "=&v"(o), "=&v"(t) : "v"(b), "v"(w), "v"(a), "s"(two));
-}
-// same with a compile-time twiddle held in SGPRs
-template <bool CONJ>
-__device__ __forceinline__ void pk_dit_k(v2f a, v2f b, v2f k, v2f &r, v2f &o) {
-    v2f t;
-    const v2f two = {2.0f, 2.0f};
-    if (CONJ)
-        asm("v_pk_fma_f32 %2, %3, %4, %5 op_sel_hi:[1,0,1]\n\t"
-            "v_pk_fma_f32 %0, %3, %4, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]\n\t"
-            "v_pk_fma_f32 %1, %5, %6, %0 neg_lo:[0,0,1] neg_hi:[0,0,1]"
-            : "=&v"(r), "=&v"(o), "=&v"(t) : "v"(b), "s"(k), "v"(a), "s"(two));
-    else
-        asm("v_pk_fma_f32 %2, %3, %4, %5 op_sel_hi:[1,0,1]\n\t"
-            "v_pk_fma_f32 %0, %3, %4, %2 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]\n\t"
-            "v_pk_fma_f32 %1, %5, %6, %0 neg_lo:[0,0,1] neg_hi:[0,0,1]"
-            : "=&v"(r), "=&v"(o), "=&v"(t) : "v"(b), "s"(k), "v"(a), "s"(two));
-}
-// base * k in one statement
-__device__ __forceinline__ v2f pk_cmul_k1(v2f a, v2f k) {
-    v2f t, r;
-    asm("v_pk_mul_f32 %1, %2, %3 op_sel_hi:[0,1]\n\t"
-        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-        : "=&v"(r), "=&v"(t) : "v"(a), "s"(k));
     return r;
 }
 
