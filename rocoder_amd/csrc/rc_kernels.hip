@@ -835,10 +835,12 @@ __device__ __forceinline__ GF hop_src(const HopParams &p, GF xc, GF xt, int64_t 
 //     bits 0..3 = frequency bits 9..12) follows without touching LDS. Residues 0 and 256 pair
 //     with themselves; thread 0 owns them and hands its 17 pairs to lanes 0..16 of wave 0 through
 //     a 32-element LDS scratch.
-//   * 4 LDS exchanges per hop instead of 6 + the middle-stage round trip. Index maps
-//     f1(n) = n + (n >> 5) and f3(n) = n + (n >> 5) + (n >> 8) keep every access pattern at most
-//     2-way conflicted on a few lanes; both are additive over disjoint bit fields, so each access is
-//     a per-thread base VGPR + an immediate offset.
+//   * 4 LDS exchanges per hop instead of 6 + the middle-stage round trip, 6 workgroup barriers
+//     instead of 13: the stores of exchanges 2 and 4 are in place (same layout and index map as the
+//     preceding load), so they need no write-after-read barrier. The index map
+//     f3(n) = n + (n >> 5) + (n >> 8) keeps every access pattern at most 2-way conflicted on a few
+//     lanes; it is additive over disjoint bit fields, so each access is a per-thread base VGPR +
+//     an immediate offset.
 #ifndef RC_V2
 #define RC_V2 1
 #endif
@@ -967,11 +969,11 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
     const int l4 = tid & 15, uu = tid >> 4;
     const int pos4 = (uu << 9) | l4;                                  // LOR = 4 layout, q = 0
     const int bE1s = f3_idx((int)(__brev((unsigned)tid) >> 24) << 5);  // brev8(t) << 5
-    const int b4f3 = f3_idx(pos4), b4f1 = f1_idx(pos4);
-    const int bAr = f1_idx(r), bBr = f1_idx(rb);
+    const int b4f3 = f3_idx(pos4);
+    const int bAr = f3_idx(r), bBr = f3_idx(rb);
     const int bE3a = f3_idx((int)(__brev((unsigned)r) >> 23) << 4);    // brev9(r) << 4
     const int bE3b = f3_idx((int)(__brev((unsigned)rb) >> 23) << 4);
-    const int bE4l = f1_idx(tid);
+    const int bE4l = f3_idx(tid);
 
     float2 tail[PH];
 #pragma unroll
@@ -1011,21 +1013,22 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         dit_stages<32, m, 0, 4, 0, false, false>(v, 0, wtab);
 #pragma unroll
         for (int q = 0; q < P; ++q) lds[bE1s + f3_idx(q)] = to_f2(v[q]);
-        __syncthreads();
+        if (!(RC_ABLATE & 32)) __syncthreads();
 #pragma unroll
         for (int q = 0; q < P; ++q) v[q] = to_v(lds[b4f3 + f3_idx(q << 4)]);
-        __syncthreads();
         dit_stages<32, m, 5, 8, 4, false, true>(v, l4, wtab);
+        // E2 store is IN PLACE (same layout, same index map as the E1 load): each thread overwrites
+        // exactly the elements it read, so no barrier is needed between the two
 #pragma unroll
-        for (int q = 0; q < P; ++q) lds[b4f1 + f1_idx(q << 4)] = to_f2(v[q]);
-        __syncthreads();
+        for (int q = 0; q < P; ++q) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);
+        if (!(RC_ABLATE & 32)) __syncthreads();
         v2f va[16], vb[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            va[q] = to_v(lds[bAr + f1_idx(RES * q)]);
-            vb[q] = to_v(lds[bBr + f1_idx(RES * q)]);
+            va[q] = to_v(lds[bAr + f3_idx(RES * q)]);
+            vb[q] = to_v(lds[bBr + f3_idx(RES * q)]);
         }
-        __syncthreads();
+        if (!(RC_ABLATE & 32)) __syncthreads();
         dit_stages<16, m, 9, 12, 9, false, true>(va, r, wtab);
         dit_stages<16, m, 9, 12, 9, false, true>(vb, rb, wtab);
 
@@ -1091,17 +1094,16 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
             lds[bE3a + f3_idx(q)] = to_f2(pa[q]);
             lds[bE3b + f3_idx(q)] = to_f2(pb[q]);
         }
-        __syncthreads();
+        if (!(RC_ABLATE & 32)) __syncthreads();
 #pragma unroll
         for (int q = 0; q < P; ++q) v[q] = to_v(lds[b4f3 + f3_idx(q << 4)]);
-        __syncthreads();
         dit_stages<32, m, 4, 8, 4, true, true>(v, l4, wtab);
 #pragma unroll
-        for (int q = 0; q < P; ++q) lds[b4f1 + f1_idx(q << 4)] = to_f2(v[q]);
-        __syncthreads();
+        for (int q = 0; q < P; ++q) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);  // in place (see E2)
+        if (!(RC_ABLATE & 32)) __syncthreads();
 #pragma unroll
-        for (int q = 0; q < P; ++q) v[q] = to_v(lds[bE4l + f1_idx(q << 8)]);
-        __syncthreads();
+        for (int q = 0; q < P; ++q) v[q] = to_v(lds[bE4l + f3_idx(q << 8)]);
+        if (!(RC_ABLATE & 32)) __syncthreads();
         dit_stages<32, m, 9, 12, 8, true, true>(v, tid, wtab);
 
         // ---- epilogue: synthesis window, overlap-add with the carried tail, store
