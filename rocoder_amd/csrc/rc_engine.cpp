@@ -163,6 +163,7 @@ struct rc_engine {
     uint64_t stats_hops = 0;
     uint32_t stats_launches = 0;
     float *d_window = nullptr, *d_env = nullptr;
+    float *d_hann_rot = nullptr;  // N = 16384 with the default window only (HopParams::hann_rot)
     float2 *d_wtab = nullptr, *d_rtab = nullptr;
     float2 *d_t1 = nullptr;  // large windows only: exp(-2 pi i j / (N/2)), j <= N/8
     uint64_t seed_mixed = 0;
@@ -207,6 +208,7 @@ rc::HopParams base_params(const rc_engine *e) {
     rc::HopParams p{};
     p.window = e->d_window;
     p.env = e->d_env;
+    p.hann_rot = e->d_hann_rot;
     p.wtab = e->d_wtab;
     p.rtab = e->d_rtab;
     p.amp = e->par.corrected_amp_factor;
@@ -516,6 +518,28 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) {
     if (cfg->window) memcpy(w.data(), cfg->window, N * sizeof(float));
     else hanning(N, w.data());                    // src/main.rs:131
     crossfade_comp(H, env.data());                // src/stretcher.rs:56
+    // the N = 16384 kernel computes the default window and the envelope in registers instead of
+    // loading them (rc_kernels.hip, HANN); a caller-supplied window gets that path only when it
+    // is the default one bit for bit
+    bool default_window = true;
+    if (cfg->window) {
+        std::vector<float> d(N);
+        hanning(N, d.data());
+        default_window = memcmp(d.data(), w.data(), N * sizeof(float)) == 0;
+    }
+    std::vector<float> hann_rot;
+    if (default_window && log2n == 14) {
+        hann_rot.resize(2 * 256 * 4);
+        for (int part = 0; part < 2; ++part) {
+            const double len1 = (double)((part ? H : N) - 1);
+            for (int t = 0; t < 256; ++t)
+                for (int b = 0; b < 2; ++b) {
+                    const double beta = 2.0 * M_PI * (double)(2 * t + b) / len1;
+                    hann_rot[(part * 256 + t) * 4 + 2 * b] = (float)cos(beta);
+                    hann_rot[(part * 256 + t) * 4 + 2 * b + 1] = (float)sin(beta);
+                }
+        }
+    }
     // twiddles in f64, rounded to f32 (as rustfft does). Windows that fit one workgroup:
     // wtab = exp(-2 pi i k / M) [M/2], rtab = exp(-2 pi i j / N) [M/4+1]. Larger windows run four
     // quarter FFTs of Ms = M/4 points: wtab is for Ms, rtab covers j <= Ms/2, t1 = exp(-2 pi i j / M).
@@ -556,6 +580,10 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) {
     RC_HIP_C(hipMalloc((void **)&e->d_rtab, rtab.size() * sizeof(float2)));
     RC_HIP_C(hipMemcpy(e->d_window, w.data(), N * sizeof(float), hipMemcpyHostToDevice));
     RC_HIP_C(hipMemcpy(e->d_env, env.data(), H * sizeof(float), hipMemcpyHostToDevice));
+    if (!hann_rot.empty()) {
+        RC_HIP_C(hipMalloc((void **)&e->d_hann_rot, hann_rot.size() * sizeof(float)));
+        RC_HIP_C(hipMemcpy(e->d_hann_rot, hann_rot.data(), hann_rot.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     RC_HIP_C(hipMemcpy(e->d_wtab, wtab.data(), wtab.size() * sizeof(float2), hipMemcpyHostToDevice));
     RC_HIP_C(hipMemcpy(e->d_rtab, rtab.data(), rtab.size() * sizeof(float2), hipMemcpyHostToDevice));
     if (big) {
@@ -573,6 +601,7 @@ void rc_engine_destroy(rc_engine *e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->d_window) (void)hipFree(e->d_window);
     if (e->d_env) (void)hipFree(e->d_env);
+    if (e->d_hann_rot) (void)hipFree(e->d_hann_rot);
     if (e->d_wtab) (void)hipFree(e->d_wtab);
     if (e->d_rtab) (void)hipFree(e->d_rtab);
     if (e->d_t1) (void)hipFree(e->d_t1);

@@ -24,6 +24,9 @@ struct HopParams {
     int64_t out_origin;    // absolute F index of out[0]
     const float *window;   // [N]
     const float *env;      // [N/2] hanning_crossfade_compensation
+    // default-window fast path of the N = 16384 kernel (null: load window/env from the tables):
+    // [2][256][4] = thread t's {cos, sin}(2 pi (2t + e) / (len - 1)), e = 0, 1; len = N, then N/2
+    const float *hann_rot;
     const float2 *wtab;    // [M/2]   exp(-2 pi i k / M), M = N/2
     const float2 *rtab;    // [M/4+1] exp(-2 pi i j / N)
     float amp;             // corrected_amp_factor

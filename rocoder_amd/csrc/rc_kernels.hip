@@ -876,6 +876,15 @@ __device__ __forceinline__ v2f vcmul(v2f a, v2f k) {  // a * k
 // DIT stages S_LO..S_HI on NREG registers: register bit (s - REG_LO) <-> position bit s; the
 // position bits below REG_LO are the runtime value l (< 2^REG_LO; HAS_L = false means l == 0).
 //   a' = a + w b, b' = a - w b, w = exp(-2 pi i (p mod 2^s) / 2^(s+1))   (conjugated when CONJ)
+// butterfly with the twiddle w' = -i w (the second half of a stage's twiddles is the first half
+// rotated by -i): alpha = w.y, beta = -w.x, so only w2r = w.xx * (-sgn) is needed, no complex product
+__device__ __forceinline__ void vdit_rot(v2f a, v2f b, v2f w, v2f w2r, v2f &r, v2f &o) {
+    const v2f t = __builtin_elementwise_fma(b, __builtin_shufflevector(w, w, 1, 1), a);
+    r = __builtin_elementwise_fma(__builtin_shufflevector(b, b, 1, 0), w2r, t);
+    const v2f two = {2.0f, 2.0f};
+    o = __builtin_elementwise_fma(a, two, -r);
+}
+
 template <int NREG, int M_LOG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L>
 __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], int l, GV2 wtab) {
     const v2f sgn = CONJ ? v2f{1.0f, -1.0f} : v2f{-1.0f, 1.0f};
@@ -883,39 +892,52 @@ __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], int l, GV2 wtab) {
     for (int s = S_LO; s <= S_HI; ++s) {
         const int rb = s - REG_LO;
         const int half = 1 << rb;
-        v2f base = {1.f, 0.f};
-        if (HAS_L) {
+        if (!HAS_L) {
+#pragma unroll
+            for (int q0 = 0; q0 < NREG; ++q0) {
+                if (q0 & half) continue;
+                const int q1 = q0 | half;
+                const int c = q0 & (half - 1);
+                const int kidx = c * (16 >> rb);  // exp(-2 pi i c / 2^(rb+1)) = W32^kidx
+                const v2f a = v[q0], b = v[q1];
+                const v2f kc = {W32_RE[kidx & 15], W32_IM[kidx & 15]};
+                if (c == 0) {
+                    v[q0] = a + b;
+                    v[q1] = a - b;
+                } else if (kidx == 8) {  // w b = -i b (forward) / +i b (inverse) = -(b.yx * sgn)
+                    const v2f ib = __builtin_shufflevector(b, b, 1, 0) * sgn;
+                    v[q0] = a - ib;
+                    v[q1] = a + ib;
+                } else {
+                    const v2f w2 = v2f{kc.y, kc.y} * sgn;
+                    vdit(a, b, kc, w2, v[q0], v[q1]);
+                }
+            }
+        } else {
             float2 bt = ldg2(wtab + (l << (M_LOG - 1 - s)));  // W_{2^(s+1)}^l
             opaque(bt);
-            base = to_v(bt);
-        }
+            const v2f base = to_v(bt);
+            // twiddles of the first half of the stage (c < half/2); the rest are these times -i
+            constexpr int NCMAX = NREG / 4 > 0 ? NREG / 4 : 1;
+            const int nc = half > 1 ? half / 2 : 1;
+            v2f tw[NCMAX], tw2[NCMAX], twr[NCMAX];
 #pragma unroll
-        for (int q0 = 0; q0 < NREG; ++q0) {
-            if (q0 & half) continue;
-            const int q1 = q0 | half;
-            const int c = q0 & (half - 1);
-            const int kidx = c * (16 >> rb);  // exp(-2 pi i c / 2^(rb+1)) = W32^kidx
-            const v2f a = v[q0], b = v[q1];
-            const v2f kc = {W32_RE[kidx & 15], W32_IM[kidx & 15]};
-            if (!HAS_L && c == 0) {
-                v[q0] = a + b;
-                v[q1] = a - b;
-            } else if (!HAS_L && kidx == 8) {  // w = -i (forward) / +i (inverse): w b = -+ i b
-                const v2f ib = __builtin_shufflevector(b, b, 1, 0) * sgn;  // conj: -i b... see below
-                // forward: w b = -i b = (b.y, -b.x) = b.yx * (1, -1) = -(b.yx * sgn_fwd)
-                // inverse: conj(w) b = +i b = (-b.y, b.x) = b.yx * (-1, 1) = -(b.yx * sgn_inv)
-                v[q0] = a - ib;
-                v[q1] = a + ib;
-            } else if (!HAS_L) {
-                const v2f w2 = v2f{kc.y, kc.y} * sgn;
-                vdit(a, b, kc, w2, v[q0], v[q1]);
-            } else {
-                v2f w;
-                if (c == 0) w = base;
-                else if (kidx == 8) w = v2f{base.y, -base.x};
-                else w = vcmul(base, kc);
-                const v2f w2 = __builtin_shufflevector(w, w, 1, 1) * sgn;
-                vdit(a, b, w, w2, v[q0], v[q1]);
+            for (int c = 0; c < NCMAX; ++c) {
+                if (c >= nc) continue;
+                const int kidx = c * (16 >> rb);
+                const v2f kc = {W32_RE[kidx & 15], W32_IM[kidx & 15]};
+                tw[c] = c == 0 ? base : vcmul(base, kc);
+                tw2[c] = __builtin_shufflevector(tw[c], tw[c], 1, 1) * sgn;
+                twr[c] = __builtin_shufflevector(tw[c], tw[c], 0, 0) * (-sgn);
+            }
+#pragma unroll
+            for (int q0 = 0; q0 < NREG; ++q0) {
+                if (q0 & half) continue;
+                const int q1 = q0 | half;
+                const int c = q0 & (half - 1);
+                const v2f a = v[q0], b = v[q1];
+                if (c < nc) vdit(a, b, tw[c], tw2[c], v[q0], v[q1]);
+                else vdit_rot(a, b, tw[c - nc], twr[c - nc], v[q0], v[q1]);
             }
         }
     }
@@ -944,7 +966,51 @@ __device__ __forceinline__ void pair_regs(float2 A, float2 Bp, float2 w, uint32_
     VB = make_float2(sx + uy, ux - sy);
 }
 
-template <bool PITCH1>
+// ---- default-window fast path: windows::hanning (src/windows.rs:4-9) and the crossfade envelope
+// (src/crossfade.rs:4-10) are both 0.5 - c cos(2 pi i / (len - 1)). Thread t touches samples
+// i = 512 q + 2 t + e, so cos(alpha_q + beta_te) = cos alpha_q cos beta_te - sin alpha_q sin beta_te:
+// the 32 (16) alpha terms are compile-time constants, the beta terms 4 (+4) floats per thread from
+// HopParams::hann_rot. Two FMAs per sample replace a table load (the loads were 70 % of the
+// kernel's vector-memory traffic).
+constexpr double cx_sin_taylor(double x) {  // |x| <= pi/2
+    double term = x, sum = x;
+    for (int n = 1; n < 16; ++n) {
+        term *= -x * x / ((2.0 * n) * (2.0 * n + 1.0));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double CX_PI = 3.14159265358979323846264338327950288;
+constexpr double cx_sin(double x) {  // 0 <= x < 2 pi + eps
+    while (x > CX_PI) x -= 2.0 * CX_PI;
+    if (x > CX_PI / 2) x = CX_PI - x;
+    if (x < -CX_PI / 2) x = -CX_PI - x;
+    return cx_sin_taylor(x);
+}
+constexpr double cx_cos(double x) { return cx_sin(x + CX_PI / 2); }
+struct HannK {
+    float c[32], s[32];
+};
+// c[q] = -amp cos(2 pi 512 q / (len - 1)), s[q] = amp sin(...): value(i) = 0.5 + c[q] cb + s[q] sb
+constexpr HannK make_hann_k(double amp, int len, int count) {
+    HannK k{};
+    for (int q = 0; q < 32; ++q) {
+        const double a = q < count ? 2.0 * CX_PI * 512.0 * q / (double)(len - 1) : 0.0;
+        k.c[q] = (float)(-amp * cx_cos(a));
+        k.s[q] = (float)(amp * cx_sin(a));
+    }
+    return k;
+}
+constexpr double cx_sqrt(double x) {
+    double r = x > 1 ? x : 1.0;
+    for (int i = 0; i < 64; ++i) r = 0.5 * (r + x / r);
+    return r;
+}
+constexpr double HANN_ENV_AMP = 1.0 - (1.0 + cx_sqrt(cx_sqrt(0.5))) * 0.5;  // crossfade.rs:5
+__device__ constexpr HannK HANN_W14 = make_hann_k(0.5, 16384, 32);
+__device__ constexpr HannK HANN_E14 = make_hann_k(HANN_ENV_AMP, 8192, 16);
+
+template <bool PITCH1, bool HANN>
 __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
     constexpr int LOG2N = 14, m = 13, M = 1 << m, H = M, T = 256, P = 32, PH = 16;
     constexpr int RES = 512;                      // residues of the last forward pass
@@ -975,6 +1041,8 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
     const int bE3b = f3_idx((int)(__brev((unsigned)rb) >> 23) << 4);
     const int bE4l = f3_idx(tid);
 
+    Stamps st;
+    st.init();
     float2 tail[PH];
 #pragma unroll
     for (int q = 0; q < PH; ++q) tail[q] = make_float2(0.f, 0.f);
@@ -989,48 +1057,73 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         v2f v[P];
         {   // load in F1 order: register q holds z[brev5(q) * T + t] * window
             GF src = hop_src(p, xc, xt, k);
-            GF win = per_hop(p.window);
-            float xr0[P], xr1[P], wr0[P], wr1[P];
+            float xr0[P], xr1[P];
 #pragma unroll
             for (int q = 0; q < P; ++q) {
                 xr0[q] = (src + 2 * T * q)[lane2];
                 xr1[q] = (src + 2 * T * q)[lane2 + 1];
             }
+            if constexpr (HANN) {
+                GF rot = per_hop(p.hann_rot);
+                const float cb0 = (rot + 0)[4 * tid], sb0 = (rot + 0)[4 * tid + 1];
+                const float cb1 = (rot + 0)[4 * tid + 2], sb1 = (rot + 0)[4 * tid + 3];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < P; ++q) {
-                wr0[q] = (win + 2 * T * q)[lane2];
-                wr1[q] = (win + 2 * T * q)[lane2 + 1];
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                for (int q = 0; q < P; ++q) {
+                    const float w0 = fmaf(HANN_W14.s[q], sb0, fmaf(HANN_W14.c[q], cb0, 0.5f));
+                    const float w1 = fmaf(HANN_W14.s[q], sb1, fmaf(HANN_W14.c[q], cb1, 0.5f));
+                    v[brev_c(q, 5)].x = xr0[q] * w0;
+                    v[brev_c(q, 5)].y = xr1[q] * w1;
+                }
+            } else {
+                GF win = per_hop(p.window);
+                float wr0[P], wr1[P];
 #pragma unroll
-            for (int q = 0; q < P; ++q) {
-                v[brev_c(q, 5)].x = xr0[q] * wr0[q];
-                v[brev_c(q, 5)].y = xr1[q] * wr1[q];
+                for (int q = 0; q < P; ++q) {
+                    wr0[q] = (win + 2 * T * q)[lane2];
+                    wr1[q] = (win + 2 * T * q)[lane2 + 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    v[brev_c(q, 5)].x = xr0[q] * wr0[q];
+                    v[brev_c(q, 5)].y = xr1[q] * wr1[q];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        st.mark(0);
         // ---- forward: F1 (bits 0..4, constants), E1, F2 (bits 5..8), E2, F3 (bits 9..12)
         dit_stages<32, m, 0, 4, 0, false, false>(v, 0, wtab);
+        st.mark(1);
 #pragma unroll
         for (int q = 0; q < P; ++q) lds[bE1s + f3_idx(q)] = to_f2(v[q]);
+        st.mark(2);
         if (!(RC_ABLATE & 32)) __syncthreads();
+        st.mark(3);
 #pragma unroll
         for (int q = 0; q < P; ++q) v[q] = to_v(lds[b4f3 + f3_idx(q << 4)]);
         dit_stages<32, m, 5, 8, 4, false, true>(v, l4, wtab);
+        st.mark(4);
         // E2 store is IN PLACE (same layout, same index map as the E1 load): each thread overwrites
         // exactly the elements it read, so no barrier is needed between the two
 #pragma unroll
         for (int q = 0; q < P; ++q) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);
+        st.mark(5);
         if (!(RC_ABLATE & 32)) __syncthreads();
+        st.mark(6);
         v2f va[16], vb[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             va[q] = to_v(lds[bAr + f3_idx(RES * q)]);
             vb[q] = to_v(lds[bBr + f3_idx(RES * q)]);
         }
+        st.mark(7);
         if (!(RC_ABLATE & 32)) __syncthreads();
+        st.mark(8);
         dit_stages<16, m, 9, 12, 9, false, true>(va, r, wtab);
         dit_stages<16, m, 9, 12, 9, false, true>(vb, rb, wtab);
+        st.mark(9);
 
         // ---- middle stage in registers: pair (A[q], B[15-q]) = bins (r + 512 q, M - that)
         if (tid == 0) {  // thread 0 owns the self-paired residues 0 and 256: hand them to wave 0
@@ -1057,6 +1150,7 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
                 vb[15 - q] = to_v(VB);
             }
         }
+        st.mark(10);
         if (tid < 64) {  // wave 0: lanes 0..16 compute thread 0's 17 pairs from the scratch
             const int i = tid;
             if (i <= 16) {
@@ -1080,6 +1174,7 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
                 }
             }
         }
+        st.mark(11);
         // ---- inverse: I1 in registers (position bits 0..3 = brev4 of the register index)
         v2f pa[16], pb[16];
 #pragma unroll
@@ -1089,25 +1184,48 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         }
         dit_stages<16, m, 0, 3, 0, true, false>(pa, 0, wtab);
         dit_stages<16, m, 0, 3, 0, true, false>(pb, 0, wtab);
+        st.mark(12);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             lds[bE3a + f3_idx(q)] = to_f2(pa[q]);
             lds[bE3b + f3_idx(q)] = to_f2(pb[q]);
         }
+        st.mark(13);
         if (!(RC_ABLATE & 32)) __syncthreads();
+        st.mark(14);
 #pragma unroll
         for (int q = 0; q < P; ++q) v[q] = to_v(lds[b4f3 + f3_idx(q << 4)]);
         dit_stages<32, m, 4, 8, 4, true, true>(v, l4, wtab);
+        st.mark(15);
 #pragma unroll
         for (int q = 0; q < P; ++q) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);  // in place (see E2)
+        st.mark(16);
         if (!(RC_ABLATE & 32)) __syncthreads();
+        st.mark(17);
 #pragma unroll
         for (int q = 0; q < P; ++q) v[q] = to_v(lds[bE4l + f3_idx(q << 8)]);
+        st.mark(18);
         if (!(RC_ABLATE & 32)) __syncthreads();
+        st.mark(19);
         dit_stages<32, m, 9, 12, 8, true, true>(v, tid, wtab);
+        st.mark(20);
 
         // ---- epilogue: synthesis window, overlap-add with the carried tail, store
-        {
+        float rot[8];  // HANN: cos/sin beta of this thread's (window e=0, e=1, envelope e=0, e=1)
+        if constexpr (HANN) {
+            GF rsrc = per_hop(p.hann_rot);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rot[i] = rsrc[4 * tid + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rot[4 + i] = (rsrc + 4 * T)[4 * tid + i];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                v[q].x *= fmaf(HANN_W14.s[q], rot[1], fmaf(HANN_W14.c[q], rot[0], 0.5f));
+                v[q].y *= fmaf(HANN_W14.s[q], rot[3], fmaf(HANN_W14.c[q], rot[2], 0.5f));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
             GF wsrc = per_hop(p.window);
             float wr0[P], wr1[P];
 #pragma unroll
@@ -1131,8 +1249,13 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
                 float er0[PH], er1[PH];
 #pragma unroll
                 for (int q = 0; q < PH; ++q) {
-                    er0[q] = (esrc + 2 * T * q)[lane2];
-                    er1[q] = (esrc + 2 * T * q)[lane2 + 1];
+                    if constexpr (HANN) {
+                        er0[q] = fmaf(HANN_E14.s[q], rot[5], fmaf(HANN_E14.c[q], rot[4], 0.5f));
+                        er1[q] = fmaf(HANN_E14.s[q], rot[7], fmaf(HANN_E14.c[q], rot[6], 0.5f));
+                    } else {
+                        er0[q] = (esrc + 2 * T * q)[lane2];
+                        er1[q] = (esrc + 2 * T * q)[lane2 + 1];
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1162,7 +1285,14 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         }
 #pragma unroll
         for (int q = 0; q < PH; ++q) tail[q] = to_f2(v[q + PH]);
+        st.mark(21);
     }
+#if RC_STAMP
+    if ((tid & 63) == 0 && p.spec) {
+        unsigned *dbg = (unsigned *)p.spec + ((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * 32;
+        for (int i = 0; i < 32; ++i) dbg[i] = st.acc[i];
+    }
+#endif
 }
 
 // Overlap-add for the user-kernel path (gather form, two terms per output sample).
@@ -1215,8 +1345,11 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
         case MODE_FUSED:
             if (RC_V2 && LOG2N == 14) {
                 const size_t lds2 = sizeof(float2) * (size_t)(f3_idx(G::M) + 8 + 32) + RC_LDS_PAD;
-                if (p.pitch == 1) hipLaunchKernelGGL((hop2_kernel<true>), grid, block, lds2, s, p);
-                else hipLaunchKernelGGL((hop2_kernel<false>), grid, block, lds2, s, p);
+                const bool hann = p.hann_rot != nullptr;
+                if (p.pitch == 1 && hann) hipLaunchKernelGGL((hop2_kernel<true, true>), grid, block, lds2, s, p);
+                else if (p.pitch == 1) hipLaunchKernelGGL((hop2_kernel<true, false>), grid, block, lds2, s, p);
+                else if (hann) hipLaunchKernelGGL((hop2_kernel<false, true>), grid, block, lds2, s, p);
+                else hipLaunchKernelGGL((hop2_kernel<false, false>), grid, block, lds2, s, p);
             } else if (p.pitch == 1)
                 hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true>), grid, block, lds, s, p);
             else
