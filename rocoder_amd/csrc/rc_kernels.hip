@@ -160,6 +160,9 @@ __device__ __forceinline__ void opaque(int &x) { asm volatile("" : "+v"(x)); }
 #ifndef RC_STAMP
 #define RC_STAMP 0
 #endif
+#ifndef RC_XPREFETCH
+#define RC_XPREFETCH 1
+#endif
 struct Stamps {
 #if RC_STAMP
     unsigned long long last;
@@ -1052,16 +1055,29 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
     if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(RC_PRIO);
 #endif
 
+    // HANN only (the table-window variant has no registers to spare): the next hop's raw input is
+    // loaded RC_XPREFETCH stages ahead and stays in flight while this hop finishes
+    constexpr bool XPF = HANN && RC_XPREFETCH != 0;
+    float xr0[P], xr1[P];
+    if constexpr (XPF) {
+        GF src = hop_src(p, xc, xt, k_begin > 0 ? k_begin - 1 : k_begin);
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            xr0[q] = (src + 2 * T * q)[lane2];
+            xr1[q] = (src + 2 * T * q)[lane2 + 1];
+        }
+    }
     for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         v2f v[P];
         {   // load in F1 order: register q holds z[brev5(q) * T + t] * window
-            GF src = hop_src(p, xc, xt, k);
-            float xr0[P], xr1[P];
+            if constexpr (!XPF) {
+                GF src = hop_src(p, xc, xt, k);
 #pragma unroll
-            for (int q = 0; q < P; ++q) {
-                xr0[q] = (src + 2 * T * q)[lane2];
-                xr1[q] = (src + 2 * T * q)[lane2 + 1];
+                for (int q = 0; q < P; ++q) {
+                    xr0[q] = (src + 2 * T * q)[lane2];
+                    xr1[q] = (src + 2 * T * q)[lane2 + 1];
+                }
             }
             if constexpr (HANN) {
                 GF rot = per_hop(p.hann_rot);
@@ -1207,7 +1223,27 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         st.mark(18);
         if (!(RC_ABLATE & 32)) __syncthreads();
         st.mark(19);
+        if constexpr (XPF && RC_XPREFETCH == 2) {  // (the last hop re-reads itself)
+            __builtin_amdgcn_sched_barrier(0);
+            GF src = hop_src(p, xc, xt, k + 1 < k_end ? k + 1 : k);
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                xr0[q] = (src + 2 * T * q)[lane2];
+                xr1[q] = (src + 2 * T * q)[lane2 + 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         dit_stages<32, m, 9, 12, 8, true, true>(v, tid, wtab);
+        if constexpr (XPF && RC_XPREFETCH == 1) {  // (the last hop re-reads itself)
+            __builtin_amdgcn_sched_barrier(0);
+            GF src = hop_src(p, xc, xt, k + 1 < k_end ? k + 1 : k);
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                xr0[q] = (src + 2 * T * q)[lane2];
+                xr1[q] = (src + 2 * T * q)[lane2 + 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         st.mark(20);
 
         // ---- epilogue: synthesis window, overlap-add with the carried tail, store
@@ -1247,19 +1283,20 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
             if constexpr (PITCH1) {
                 GFW dst = outc + (g0 - p.out_origin);
                 float er0[PH], er1[PH];
+                if constexpr (!HANN) {
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) {
+                        er0[q] = (esrc + 2 * T * q)[lane2];
+                        er1[q] = (esrc + 2 * T * q)[lane2 + 1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int q = 0; q < PH; ++q) {
                     if constexpr (HANN) {
                         er0[q] = fmaf(HANN_E14.s[q], rot[5], fmaf(HANN_E14.c[q], rot[4], 0.5f));
                         er1[q] = fmaf(HANN_E14.s[q], rot[7], fmaf(HANN_E14.c[q], rot[6], 0.5f));
-                    } else {
-                        er0[q] = (esrc + 2 * T * q)[lane2];
-                        er1[q] = (esrc + 2 * T * q)[lane2 + 1];
                     }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < PH; ++q) {
                     float2 o;  // stretcher.rs:97-100 operation order
                     o.x = (v[q].x + tail[q].x) * er0[q] * p.amp;
                     o.y = (v[q].y + tail[q].y) * er1[q] * p.amp;
