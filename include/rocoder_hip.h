@@ -93,7 +93,11 @@ int rc_derive_params(const rc_config *cfg, rc_params *out);
 size_t rc_offline_output_len(const rc_config *cfg, size_t in_len);
 /* Phase-source spec (replaces rand::thread_rng at src/fft.rs:64-67), exposed for tests. */
 uint64_t rc_phase_key(uint64_t seed, uint32_t channel, uint64_t hop);
-uint32_t rc_phase_hash(uint64_t key, uint32_t bin);
+uint32_t rc_phase_hash(uint64_t key, uint32_t counter);
+/* theta in [0, pi) of bin `bin` of an n_bins-point spectrum: bins b < n_bins/2 take the top 23 bits
+ * of rc_phase_hash(key, b) (rand 0.8.5's f32 draw), bins b >= n_bins/2 the low 16 bits of
+ * rc_phase_hash(key, b - n_bins/2). */
+float rc_phase_theta(uint64_t key, uint32_t bin, uint32_t n_bins);
 
 /* Stretcher::new for all channels (src/main.rs:133-153, src/stretcher.rs:30-76) +
  * ReFFT::new (src/fft.rs:25-40): builds window/envelope/twiddle tables on the device. */

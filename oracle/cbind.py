@@ -56,7 +56,7 @@ def lib() -> C.CDLL:
     L.rco_phase_key.restype = C.c_uint64
     L.rco_phase_hash.argtypes = [C.c_uint64, C.c_uint32]
     L.rco_phase_hash.restype = C.c_uint32
-    L.rco_phase_theta.argtypes = [C.c_uint64, C.c_uint32]
+    L.rco_phase_theta.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
     L.rco_phase_theta.restype = C.c_float
     L.rco_refft_new.argtypes = [fp, sz]
     L.rco_refft_new.restype = C.c_void_p
@@ -163,9 +163,9 @@ def phase_hash(key: int, bins) -> np.ndarray:
     return np.array([L.rco_phase_hash(key, int(b)) for b in np.atleast_1d(bins)], np.uint32)
 
 
-def phase_theta(key: int, bins) -> np.ndarray:
+def phase_theta(key: int, bins, n_bins: int) -> np.ndarray:
     L = lib()
-    return np.array([L.rco_phase_theta(key, int(b)) for b in np.atleast_1d(bins)], np.float32)
+    return np.array([L.rco_phase_theta(key, int(b), n_bins) for b in np.atleast_1d(bins)], np.float32)
 
 
 def wrap_kernel(pyfunc):

@@ -41,11 +41,17 @@ def phase_hash(key: int, bins) -> np.ndarray:
     return x
 
 
-def phase_theta(key: int, bins) -> np.ndarray:
-    """theta in [0, pi) as f32: (h >> 9) * 2^-23 * PI_f32 (fft.rs:13,67; rand 0.8.5 UniformFloat)."""
-    h = phase_hash(key, bins)
-    u = (h >> np.uint32(9)).astype(np.float32) * np.float32(1.0 / 8388608.0)
-    return (u * PI_F32).astype(np.float32)
+def phase_theta(key: int, bins, n_bins: int) -> np.ndarray:
+    """theta in [0, pi) as f32 (fft.rs:13,67; rand 0.8.5 UniformFloat). Bins b < n_bins/2 take the
+    top 23 bits of hash(b): (h >> 9) * 2^-23 * PI_f32; bins b >= n_bins/2 take the low 16 bits of
+    hash(b - n_bins/2): (h & 0xFFFF) * 2^-16 * PI_f32."""
+    bins = np.asarray(bins, dtype=np.uint32)
+    half = np.uint32(n_bins // 2)
+    upper = bins >= half
+    h = phase_hash(key, np.where(upper, bins - half, bins))
+    u_lo = (h >> np.uint32(9)).astype(np.float32) * np.float32(1.0 / 8388608.0)
+    u_up = (h & np.uint32(0xFFFF)).astype(np.float32) * np.float32(1.0 / 65536.0)
+    return (np.where(upper, u_up, u_lo).astype(np.float32) * PI_F32).astype(np.float32)
 
 
 # --------------------------------------------------------------------------- tables
@@ -110,7 +116,7 @@ def resynth(samples: np.ndarray, window: np.ndarray, key: int, kernel=None, time
                 X = Y.astype(np.complex128)
         except Exception:
             pass  # panic -> noop (fft.rs:100-106)
-    theta = phase_theta(key, np.arange(n)).astype(np.float64)
+    theta = phase_theta(key, np.arange(n), n).astype(np.float64)
     Z = np.abs(X) * (np.cos(theta) + 1j * np.sin(theta))  # fft.rs:65-68
     y = np.fft.ifft(Z).real  # ifft = unnormalised inverse / N  (fft.rs:69,72)
     out = y * window.astype(np.float64)

@@ -87,8 +87,10 @@ size_t rco_resample(const float *in, size_t n, int factor, float *out) {
 /* makes that (u32 >> 9) * 2^-23 * (high - low) + low. Here the u32 comes from */
 /* a counter-based hash of (seed, channel, hop, bin) so CPU and GPU agree:     */
 /*   key  = mix64(mix64(seed) ^ ((channel << 40) | hop))   (splitmix64 steps)  */
-/*   h    = lowbias32(bin * (hi32(key) | 1) + lo32(key))                       */
-/*   theta = fl32((h >> 9) * 2^-23) * PI_f32                                   */
+/*   h(c) = lowbias32(c * (hi32(key) | 1) + lo32(key))                         */
+/* One hash serves two bins, b and b + N/2 (half the hashing on the GPU):      */
+/*   b <  N/2: theta = fl32((h(b) >> 9) * 2^-23) * PI_f32   (rand's 23 bits)   */
+/*   b >= N/2: theta = fl32((h(b - N/2) & 0xFFFF) * 2^-16) * PI_f32            */
 /* ------------------------------------------------------------------------- */
 static uint64_t rco_mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
@@ -113,10 +115,17 @@ uint32_t rco_phase_hash(uint64_t key, uint32_t bin) {
     return x;
 }
 
-float rco_phase_theta(uint64_t key, uint32_t bin) {
-    uint32_t h = rco_phase_hash(key, bin);
-    float u = (float)(h >> 9) * (1.0f / 8388608.0f); /* exact: 23-bit mantissa */
-    return u * RCO_PI_F32;                            /* * (high - low) + low, low = 0 */
+float rco_phase_theta(uint64_t key, uint32_t bin, uint32_t n_bins) {
+    uint32_t half = n_bins / 2;
+    float u;
+    if (bin < half) {
+        uint32_t h = rco_phase_hash(key, bin);
+        u = (float)(h >> 9) * (1.0f / 8388608.0f); /* exact: 23-bit mantissa */
+    } else {
+        uint32_t h = rco_phase_hash(key, bin - half);
+        u = (float)(h & 0xFFFFu) * (1.0f / 65536.0f); /* exact */
+    }
+    return u * RCO_PI_F32; /* * (high - low) + low, low = 0 */
 }
 
 /* ------------------------------------------------------------------------- */
@@ -279,7 +288,7 @@ void rco_refft_resynth_from_spectrum(rco_refft *r, const float *spec_reim, uint6
     const size_t n = r->window_len;
     float *buf = r->buf;
     for (size_t j = 0; j < n; j++) {
-        float theta = rco_phase_theta(phase_key, (uint32_t)j);
+        float theta = rco_phase_theta(phase_key, (uint32_t)j, (uint32_t)n);
         /* Complex32::new(0.0, theta).exp() == from_polar(exp(0.0), theta)
          * == (1.0 * cos theta, 1.0 * sin theta)   (num-complex 0.4.6) */
         float er = 1.0f * cosf(theta);

@@ -52,7 +52,8 @@ size_t rco_resample(const float *in, size_t n, int factor, float *out); /* resam
 /* ---- phase source (replaces rand::thread_rng, src/fft.rs:64-67) ------------ */
 uint64_t rco_phase_key(uint64_t seed, uint32_t channel, uint64_t hop);
 uint32_t rco_phase_hash(uint64_t key, uint32_t bin);
-float rco_phase_theta(uint64_t key, uint32_t bin); /* in [0, pi): fft.rs:13 TWO_PI == PI */
+/* in [0, pi): fft.rs:13 TWO_PI == PI. Bins b and b + n_bins/2 share one hash (see the .c file) */
+float rco_phase_theta(uint64_t key, uint32_t bin, uint32_t n_bins);
 
 /* ---- src/fft.rs : ReFFT ---------------------------------------------------- */
 typedef struct rco_refft rco_refft;

@@ -63,6 +63,7 @@ SYMBOLS = {
     "rc_offline_output_len": (_sz, [C.POINTER(rc_config), _sz]),
     "rc_phase_key": (C.c_uint64, [C.c_uint64, C.c_uint32, C.c_uint64]),
     "rc_phase_hash": (C.c_uint32, [C.c_uint64, C.c_uint32]),
+    "rc_phase_theta": (C.c_float, [C.c_uint64, C.c_uint32, C.c_uint32]),
     "rc_engine_create": (C.c_int, [C.POINTER(rc_config), C.POINTER(_eng)]),
     "rc_engine_destroy": (None, [_eng]),
     "rc_engine_get_params": (C.c_int, [_eng, C.POINTER(rc_params)]),

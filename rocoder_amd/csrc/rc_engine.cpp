@@ -480,6 +480,13 @@ uint32_t rc_phase_hash(uint64_t key, uint32_t bin) {
     x ^= x >> 15;
     return x;
 }
+float rc_phase_theta(uint64_t key, uint32_t bin, uint32_t n_bins) {
+    const uint32_t half = n_bins / 2;
+    const bool upper = bin >= half;
+    const uint32_t h = rc_phase_hash(key, upper ? bin - half : bin);
+    const float u = upper ? (float)(h & 0xFFFFu) * (1.0f / 65536.0f) : (float)(h >> 9) * (1.0f / 8388608.0f);
+    return u * 3.14159265358979323846f;
+}
 
 int rc_engine_create(const rc_config *cfg, rc_engine **out) {
     if (!out) return fail(RC_EINVAL, "null out");

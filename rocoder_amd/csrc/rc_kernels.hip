@@ -371,40 +371,57 @@ __device__ __forceinline__ PhaseKey make_phase_key(uint64_t seed_mixed, uint32_t
     k.mul = (uint32_t)(key >> 32) | 1u;
     return k;
 }
-// returns (-cos theta, -sin theta), theta = pi * (h >> 9) * 2^-23:
-// v_cos/v_sin take revolutions; f = 0.5 + (h>>9) 2^-24 in [0.5, 1) => 2 pi f = pi + theta.
-__device__ __forceinline__ void phase_ncs(PhaseKey k, uint32_t bin, float &nc, float &ns) {
-    if (RC_ABLATE & 1) {
-        nc = __uint_as_float(0x3F000000u | (bin + k.k0));
-        ns = nc + 1.0f;
-        return;
-    }
-    uint32_t x = bin * k.mul + k.k0;
+// One 32-bit hash serves the two bins b < M (its top 23 bits) and b + M (its low 16 bits), M = N/2:
+//   theta(b)     = pi * (h >> 9)     * 2^-23          theta(b + M) = pi * (h & 0xFFFF) * 2^-16
+// The phasors come out negated: v_cos/v_sin take revolutions, and f = 0.5 + theta / (2 pi) in
+// [0.5, 1) is assembled in the mantissa (2 pi f = pi + theta).
+__device__ __forceinline__ uint32_t phase_hash_x(uint32_t x) {
     x ^= x >> 16;
     x *= 0x21F0AAADu;
     x ^= x >> 15;
     x *= 0x735A2D97u;
     x ^= x >> 15;
-    const float f = __uint_as_float(0x3F000000u | (x >> 9));
-    nc = __builtin_amdgcn_cosf(f);
-    ns = __builtin_amdgcn_sinf(f);
+    return x;
 }
-
-// hash finaliser on a prepared counter x = bin * mul + k0 (see phase_ncs)
-__device__ __forceinline__ void phase_ncs_x(uint32_t x, float &nc, float &ns) {
+__device__ __forceinline__ float phase_rev_lower(uint32_t h) { return __uint_as_float(0x3F000000u | (h >> 9)); }
+__device__ __forceinline__ float phase_rev_upper(uint32_t h) {
+    return __uint_as_float(0x3F000000u | ((h & 0xFFFFu) << 7));
+}
+// counter x = c * mul + k0 of c < M: (-cos, -sin) of bin c (lo*) and of bin c + M (up*)
+__device__ __forceinline__ void phase_ncs2_x(uint32_t x, float &lo_nc, float &lo_ns, float &up_nc,
+                                             float &up_ns) {
     if (RC_ABLATE & 1) {
-        nc = __uint_as_float(0x3F000000u | (x & 0xFFFFu));
-        ns = nc + 1.0f;
+        lo_nc = __uint_as_float(0x3F000000u | (x & 0xFFFFu));
+        lo_ns = lo_nc + 1.0f;
+        up_nc = lo_nc + 2.0f;
+        up_ns = lo_nc + 3.0f;
         return;
     }
-    x ^= x >> 16;
-    x *= 0x21F0AAADu;
-    x ^= x >> 15;
-    x *= 0x735A2D97u;
-    x ^= x >> 15;
-    const float f = __uint_as_float(0x3F000000u | (x >> 9));
-    nc = __builtin_amdgcn_cosf(f);
-    ns = __builtin_amdgcn_sinf(f);
+    const uint32_t h = phase_hash_x(x);
+    const float fl = phase_rev_lower(h), fu = phase_rev_upper(h);
+    lo_nc = __builtin_amdgcn_cosf(fl);
+    lo_ns = __builtin_amdgcn_sinf(fl);
+    up_nc = __builtin_amdgcn_cosf(fu);
+    up_ns = __builtin_amdgcn_sinf(fu);
+}
+// the four phases of the pair (ja, M - ja), ja < M: bins ja, N - ja, M - ja, M + ja from the two
+// hashes of counters ja and M - ja. ja == 0 wraps: N - 0 is bin 0 again and M - 0 is bin M.
+__device__ __forceinline__ void phase_quad(PhaseKey k, uint32_t ja, uint32_t M, float &c1, float &s1,
+                                           float &c2, float &s2, float &c3, float &s3, float &c4,
+                                           float &s4) {
+    const uint32_t ha = phase_hash_x(ja * k.mul + k.k0);
+    const uint32_t hb = phase_hash_x(((M - ja) & (M - 1)) * k.mul + k.k0);
+    const float f1 = phase_rev_lower(ha), f4 = phase_rev_upper(ha);
+    const float fbl = phase_rev_lower(hb), fbu = phase_rev_upper(hb);
+    const float f2 = ja ? fbu : fbl, f3 = ja ? fbl : fbu;
+    c1 = __builtin_amdgcn_cosf(f1);
+    s1 = __builtin_amdgcn_sinf(f1);
+    c2 = __builtin_amdgcn_cosf(f2);
+    s2 = __builtin_amdgcn_sinf(f2);
+    c3 = __builtin_amdgcn_cosf(f3);
+    s3 = __builtin_amdgcn_sinf(f3);
+    c4 = __builtin_amdgcn_cosf(f4);
+    s4 = __builtin_amdgcn_sinf(f4);
 }
 
 // ---- one (ja, M - ja) bin pair -----------------------------------------------------------
@@ -427,10 +444,7 @@ __device__ __forceinline__ void pair_synth(float m1a, float m1b, float m2a, floa
                                            float2 &VB) {
     constexpr uint32_t N = 1u << LOG2N, M = N / 2;
     float c1, s1, c2, s2, c3, s3, c4, s4;
-    phase_ncs(key, ja, c1, s1);
-    phase_ncs(key, (N - ja) & (N - 1), c2, s2);
-    phase_ncs(key, M - ja, c3, s3);
-    phase_ncs(key, M + ja, c4, s4);
+    phase_quad(key, ja, M, c1, s1, c2, s2, c3, s3, c4, s4);
     m1a *= nkappa;
     m1b *= nkappa;
     m2a *= nkappa;
@@ -550,10 +564,9 @@ __device__ __forceinline__ void middle_fused(float2 *lds, int tid, PhaseKey key,
     if (tid == 0) {  // redirect the stand-in's writes (uniform per wave except wave 0)
         ia[0] = ib[0] = ic[0] = id[0] = DUMMY;
     }
-    // counters of the four phases of a pair follow from one multiply:
-    //   x(b) = b*mul + k0 ;  x(N-b) = (N*mul + 2 k0) - x(b) ;  x(M-b) = (M*mul + 2 k0) - x(b) ;
-    //   x(M+b) = M*mul + x(b)
-    const uint32_t cN = N * key.mul + 2u * key.k0, cM = M * key.mul + 2u * key.k0, cP = M * key.mul;
+    // the two counters of a pair follow from one multiply: x(b) = b*mul + k0 serves bins b and
+    // M + b, x(M-b) = (M*mul + 2 k0) - x(b) serves bins M - b and N - b
+    const uint32_t cM = M * key.mul + 2u * key.k0;
     const float nkappa = -0.25f / (float)N;
 #pragma unroll
     for (int s = 0; s < QN; ++s) {
@@ -570,10 +583,8 @@ __device__ __forceinline__ void middle_fused(float2 *lds, int tid, PhaseKey key,
             float m1 = cabs_fast(X1) * nkappa, m2 = cabs_fast(X2c) * nkappa;
             const uint32_t x1 = jb * key.mul + key.k0;
             float c1, s1, c2, s2, c3, s3, c4, s4;
-            phase_ncs_x(x1, c1, s1);
-            phase_ncs_x(cN - x1, c2, s2);
-            phase_ncs_x(cM - x1, c3, s3);
-            phase_ncs_x(cP + x1, c4, s4);
+            phase_ncs2_x(x1, c1, s1, c4, s4);       // bins jb and M + jb
+            phase_ncs2_x(cM - x1, c3, s3, c2, s2);  // bins M - jb and N - jb
             const float px = m1 * (c1 + c2), py = m1 * (s1 - s2);  // Zs[jb]
             const float qx = m2 * (c3 + c4), qy = m2 * (s4 - s3);  // conj(Zs[M-jb])
             const float sx = px + qx, sy = py + qy;
@@ -951,16 +962,18 @@ template <int LOG2N>
 __device__ __forceinline__ void pair_regs(float2 A, float2 Bp, float2 w, uint32_t x1, PhaseKey key,
                                           float2 &VA, float2 &VB, bool dc = false) {
     constexpr uint32_t N = 1u << LOG2N, M = N / 2;
-    const uint32_t cN = N * key.mul + 2u * key.k0, cM = M * key.mul + 2u * key.k0, cP = M * key.mul;
+    const uint32_t cM = M * key.mul + 2u * key.k0;
     const float nkappa = -0.25f / (float)N;
     float2 X1, X2c;
     pair_analyze(A, Bp, w, X1, X2c);
     const float m1 = cabs_fast(X1) * nkappa, m2 = cabs_fast(X2c) * nkappa;
     float c1, s1, c2, s2, c3, s3, c4, s4;
-    phase_ncs_x(x1, c1, s1);
-    phase_ncs_x(dc ? x1 : cN - x1, c2, s2);  // bin N - ja; ja == 0 wraps onto bin 0 itself
-    phase_ncs_x(cM - x1, c3, s3);
-    phase_ncs_x(cP + x1, c4, s4);
+    phase_ncs2_x(x1, c1, s1, c4, s4);       // bins ja and M + ja
+    phase_ncs2_x(cM - x1, c3, s3, c2, s2);  // bins M - ja and N - ja
+    if (dc) {  // ja == 0 wraps: N - 0 is bin 0 again, M - 0 is bin M
+        c2 = c1, s2 = s1;
+        c3 = c4, s3 = s4;
+    }
     const float px = m1 * (c1 + c2), py = m1 * (s1 - s2);
     const float qx = m2 * (c3 + c4), qy = m2 * (s4 - s3);
     const float sx = px + qx, sy = py + qy, rx = px - qx, ry = py - qy;
@@ -1536,10 +1549,7 @@ __global__ __launch_bounds__(256) void big_b_kernel(const BigParams p) {
         pair_analyze(A, Bp, w, X1, X2c);
         float m1 = cabs_fast(X1) * nkappa, m2 = cabs_fast(X2c) * nkappa;
         float c1, s1, c2, s2, c3, s3, c4, s4;
-        phase_ncs(key, J, c1, s1);
-        phase_ncs(key, (N - J) & (N - 1), c2, s2);
-        phase_ncs(key, M - J, c3, s3);
-        phase_ncs(key, M + J, c4, s4);
+        phase_quad(key, J, M, c1, s1, c2, s2, c3, s3, c4, s4);
         const float px = m1 * (c1 + c2), py = m1 * (s1 - s2);
         const float qx = m2 * (c3 + c4), qy = m2 * (s4 - s3);
         const float sx = px + qx, sy = py + qy, rx = px - qx, ry = py - qy;

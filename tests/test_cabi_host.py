@@ -84,6 +84,8 @@ def test_phase_source_spec_matches_oracle(goldens):
         k = L.rc_phase_key(seed, ch, hop)
         assert k == onp.phase_key(seed, ch, hop)
         assert L.rc_phase_hash(k, b) == int(onp.phase_hash(k, [b])[0])
+        for n in (32, 16384, 65536):
+            assert np.float32(L.rc_phase_theta(k, b % n, n)) == onp.phase_theta(k, [b % n], n)[0]
 
 
 def test_compute_fails_loudly_without_gpu():

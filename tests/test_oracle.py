@@ -134,20 +134,33 @@ def test_phase_source_known_answers(goldens):
     bins = z["phase/bins"]
     assert np.array_equal(oc.phase_hash(key, bins), z["phase/hash"])
     assert np.array_equal(onp.phase_hash(key, bins), z["phase/hash"])
-    assert np.array_equal(oc.phase_theta(key, bins), z["phase/theta"])
+    assert np.array_equal(oc.phase_theta(key, bins, 65536), z["phase/theta"])
+    assert np.array_equal(onp.phase_theta(key, bins, 65536), z["phase/theta"])
+    low = bins[bins < 16384]
+    assert np.array_equal(oc.phase_theta(key, low, 16384), z["phase/theta16384"])
+    # bins below n/2 keep rand's 23-bit draw of their own hash; bin b + n/2 reuses hash(b)'s low half
+    h = onp.phase_hash(key, [3])[0]
+    assert oc.phase_theta(key, [3], 1024)[0] == np.float32(h >> 9) * np.float32(2.0 ** -23) * np.float32(np.pi)
+    assert oc.phase_theta(key, [3 + 512], 1024)[0] == np.float32(h & 0xFFFF) * np.float32(2.0 ** -16) * np.float32(np.pi)
 
 
 def test_phase_source_range_and_statistics():
     key = oc.phase_key(123, 0, 0)
-    th = onp.phase_theta(key, np.arange(1 << 16))
+    th = onp.phase_theta(key, np.arange(1 << 16), 1 << 16)
     assert th.min() >= 0.0 and th.max() < np.float32(np.pi)  # fft.rs:13: TWO_PI == PI
     assert abs(th.mean() - np.pi / 2) < 0.02
     # channels / hops are independent streams (fft.rs:64 draws sequentially across channels)
-    th2 = onp.phase_theta(oc.phase_key(123, 1, 0), np.arange(1 << 16))
-    th3 = onp.phase_theta(oc.phase_key(123, 0, 1), np.arange(1 << 16))
+    th2 = onp.phase_theta(oc.phase_key(123, 1, 0), np.arange(1 << 16), 1 << 16)
+    th3 = onp.phase_theta(oc.phase_key(123, 0, 1), np.arange(1 << 16), 1 << 16)
     for other in (th2, th3):
         c = np.corrcoef(th, other)[0, 1]
         assert abs(c) < 0.02
+    # the two bins that share a hash are uncorrelated, and the 16-bit half is uniform too
+    lo, up = th[: 1 << 15], th[1 << 15:]
+    assert abs(np.corrcoef(lo, up)[0, 1]) < 0.02
+    assert abs(up.mean() - np.pi / 2) < 0.02
+    hist = np.histogram(up, bins=16, range=(0, np.pi))[0]
+    assert hist.min() > 0.9 * up.size / 16 and hist.max() < 1.1 * up.size / 16
 
 
 # ------------------------------------------------------------------ one hop (fft.rs)

@@ -78,7 +78,7 @@ def pair(A, Bp, w, ja, key, N, M, kappa):
     X1 = E - 1j * Tt
     X2c = E + 1j * Tt
     m1, m2 = np.abs(X1), np.abs(X2c)
-    th = lambda b: onp.phase_theta(key, np.asarray(b) % N).astype(np.float64)  # noqa: E731
+    th = lambda b: onp.phase_theta(key, np.asarray(b) % N, N).astype(np.float64)  # noqa: E731
     t1, t2, t3, t4 = th(ja), th(N - ja), th(M - ja), th(M + ja)
     Pz = (m1 * kappa) * ((np.cos(t1) + np.cos(t2)) + 1j * (np.sin(t1) - np.sin(t2)))
     Q = (m2 * kappa) * ((np.cos(t3) + np.cos(t4)) + 1j * (np.sin(t4) - np.sin(t3)))
