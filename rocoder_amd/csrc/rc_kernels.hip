@@ -1324,8 +1324,16 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
 #pragma unroll
                 for (int q = 0; q < PH; ++q) {
                     const uint32_t i0 = 2u * (uint32_t)(t2 + T * q);
-                    const float o0 = (v[q].x + tail[q].x) * (esrc + 2 * T * q)[lane2] * p.amp;
-                    const float o1 = (v[q].y + tail[q].y) * (esrc + 2 * T * q)[lane2 + 1] * p.amp;
+                    float e0, e1;
+                    if constexpr (HANN) {
+                        e0 = fmaf(HANN_E14.s[q], rot[5], fmaf(HANN_E14.c[q], rot[4], 0.5f));
+                        e1 = fmaf(HANN_E14.s[q], rot[7], fmaf(HANN_E14.c[q], rot[6], 0.5f));
+                    } else {
+                        e0 = (esrc + 2 * T * q)[lane2];
+                        e1 = (esrc + 2 * T * q)[lane2 + 1];
+                    }
+                    const float o0 = (v[q].x + tail[q].x) * e0 * p.amp;
+                    const float o1 = (v[q].y + tail[q].y) * e1 * p.amp;
                     const uint32_t a0 = kr + i0, a1 = a0 + 1;
                     const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
                     if (d0 * pitch == a0) dst[d0] = o0;

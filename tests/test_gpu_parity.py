@@ -181,6 +181,30 @@ def test_amplitude_and_custom_window():
     assert_parity(got, np.concatenate(ref), "custom window")
 
 
+@pytest.mark.parametrize("p", [1, 3])
+@pytest.mark.parametrize("kind", ["sqrt_hann", "explicit_hanning"])
+def test_16384_table_window_and_default_window_detection(kind, p):
+    """N = 16384 has two kernel variants: the default hanning window computed in registers, and
+    any other window loaded from its table. A caller-supplied window takes the first only when
+    it is windows::hanning bit for bit (then the result equals the window=None run exactly)."""
+    ra = _engine_mod()
+    N, f = 16384, 8.0
+    x = onp.synth_input(5, 60000)
+    w = oc.hanning(N) if kind == "explicit_hanning" else np.sqrt(oc.hanning(N)).astype(np.float32)
+    with ra.Engine(window_len=N, factor=f, pitch_multiple=p, window=w, seed=21) as e:
+        got = e.stretch_host(x[None])[0]
+    s = oc.Stretcher(factor=f, pitch_multiple=p, window=w, seed=21)
+    s.send(x)
+    s.close_input()
+    ref = []
+    while not s.is_done():
+        ref.append(s.next_window())
+    assert_parity(got, np.concatenate(ref), f"16384 window {kind}")
+    if kind == "explicit_hanning":
+        with ra.Engine(window_len=N, factor=f, pitch_multiple=p, seed=21) as e:
+            assert np.array_equal(e.stretch_host(x[None])[0], got)
+
+
 # ------------------------------------------------------------------ user frequency kernel
 def test_gain_kernel_is_exactly_linear():
     # .norm() is linear: the x2.0 kernel config (BASELINE C4) must give 2 * F for the same phases
