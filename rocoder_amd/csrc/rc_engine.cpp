@@ -170,7 +170,7 @@ struct rc_engine {
     int n_cu = 256;
     std::vector<Channel> ch;
     // scratch
-    DevBuf d_in, d_out, d_spec, d_ybuf, d_tail, d_hop_in, d_hop_out, d_xtail;
+    DevBuf d_in, d_out, d_spec, d_ybuf, d_ysub, d_tail, d_hop_in, d_hop_out, d_xtail;
     std::vector<float> h_spec, h_spec2, h_io;
     bool tail_zeroed = false;
 };
@@ -218,6 +218,31 @@ rc::HopParams base_params(const rc_engine *e) {
     p.stagger_div = (uint32_t)std::max(1, e->n_cu);
     return p;
 }
+
+// the large-window kernels take the same description of the input as the hop kernels
+rc::BigParams big_params(const rc_engine *e, const rc::HopParams &p) {
+    rc::BigParams b{};
+    b.x = p.x;
+    b.in_stride = p.in_stride;
+    b.in_origin = p.in_origin;
+    b.xtail = p.xtail;
+    b.tail_stride = p.tail_stride;
+    b.tail_origin = p.tail_origin;
+    b.tail_hop_first = p.tail_hop_first;
+    b.window = e->d_window;
+    b.wtab_sub = e->d_wtab;
+    b.t1 = e->d_t1;
+    b.rtab = e->d_rtab;
+    b.step = p.step;
+    b.seed_mixed = p.seed_mixed;
+    b.ch_first = p.ch_first;
+    b.n_channels = p.n_channels;
+    b.hop_first = p.hop_first;
+    b.hop_count = p.hop_count;
+    b.log2n = (uint32_t)e->log2n;
+    return b;
+}
+
 
 int check_gpu_path(const rc_engine *e) {
     (void)e;
@@ -329,7 +354,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     // streaming batches do not depend on call history.
     const bool big = e->log2n > 14;
     const uint32_t hpw = e->par.hops_per_window;
-    const size_t per_hop = (size_t)N * (big ? 12 : 12);  // spectrum / quarter-FFT scratch + y
+    const size_t per_hop = (size_t)N * (big && e->cfg.kernel ? 16 : 12);  // spectrum, quarter-FFT scratch, y
     int64_t chunk_max = (int64_t)((((size_t)(e->cfg.kernel ? 192 : 1024)) << 20) / (per_hop * n_channels));
     chunk_max = std::max<int64_t>(hpw, std::min<int64_t>(chunk_max / hpw * hpw, 32768));
     int rc = e->d_tail.reserve((size_t)e->cfg.channels * H * sizeof(float));
@@ -342,40 +367,35 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     auto run_chunk = [&](int64_t k0, int64_t kc, bool tail_only) -> int {
         int rcc;
         const size_t spec_floats = (size_t)n_channels * kc * N * 2;
-        if ((rcc = e->d_spec.reserve(spec_floats * sizeof(float)))) return rcc;
+        if ((!big || e->cfg.kernel) && (rcc = e->d_spec.reserve(spec_floats * sizeof(float)))) return rcc;
         if ((rcc = e->d_ybuf.reserve((size_t)n_channels * kc * N * sizeof(float)))) return rcc;
+        rc::HopParams q = p;
+        q.spec = (float2 *)e->d_spec.p;
+        q.ybuf = (float *)e->d_ybuf.p;
+        q.ch_first = ch_first;
+        q.n_channels = n_channels;
+        q.hop_first = k0;
+        q.hop_count = kc;
+        rc::BigParams b{};
         if (big) {
-            rc::BigParams b{};
-            b.x = p.x;
-            b.in_stride = p.in_stride;
-            b.in_origin = p.in_origin;
-            b.xtail = p.xtail;
-            b.tail_stride = p.tail_stride;
-            b.tail_origin = p.tail_origin;
-            b.tail_hop_first = p.tail_hop_first;
-            b.window = e->d_window;
-            b.wtab_sub = e->d_wtab;
-            b.t1 = e->d_t1;
-            b.rtab = e->d_rtab;
-            b.ysub = (float2 *)e->d_spec.p;
-            b.ybuf = (float *)e->d_ybuf.p;
-            b.step = p.step;
-            b.seed_mixed = p.seed_mixed;
-            b.ch_first = ch_first;
-            b.n_channels = n_channels;
-            b.hop_first = k0;
-            b.hop_count = kc;
-            b.log2n = (uint32_t)e->log2n;
+            if ((rcc = e->d_ysub.reserve((size_t)n_channels * kc * N * sizeof(float)))) return rcc;
+            b = big_params(e, q);
+            b.ysub = (float2 *)e->d_ysub.p;
+            b.ybuf = q.ybuf;
+            b.spec = q.spec;
+        } else {
+            plan_runs(e, n_channels, kc, &q.runs_per_channel, &q.run_len);
+        }
+        if (big && !e->cfg.kernel) {
             for (int stage = 0; stage < 3; ++stage) RC_HIP(rc::launch_big(stage, b, s));
             launches += 3;
         } else {
-            rc::HopParams q = p;
-            q.spec = (float2 *)e->d_spec.p;
-            q.ybuf = (float *)e->d_ybuf.p;
-            q.hop_first = k0;
-            q.hop_count = kc;
-            plan_runs(e, n_channels, kc, &q.runs_per_channel, &q.run_len);
-            RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, q, s));
+            if (big) {
+                RC_HIP(rc::launch_big(0, b, s));
+                RC_HIP(rc::launch_big(1, b, s, rc::MODE_FORWARD));
+            } else {
+                RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, q, s));
+            }
             if (e->cfg.kernel) {
                 e->h_spec.resize(spec_floats);
                 e->h_spec2.resize((size_t)N * 2);
@@ -397,8 +417,14 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
                 RC_HIP(hipMemcpyAsync(e->d_spec.p, e->h_spec.data(), spec_floats * sizeof(float),
                                       hipMemcpyHostToDevice, s));
             }
-            RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, q, s));
-            launches += 2;
+            if (big) {
+                RC_HIP(rc::launch_big(1, b, s, rc::MODE_RESYNTH));
+                RC_HIP(rc::launch_big(2, b, s));
+                launches += 4;
+            } else {
+                RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, q, s));
+                launches += 2;
+            }
         }
         rc::OlaParams o{};
         o.ybuf = (const float *)e->d_ybuf.p;
@@ -436,6 +462,36 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         e->stats_hops = (uint64_t)hop_count * n_channels;
         e->stats_launches = launches;
     }
+    return RC_OK;
+}
+
+// one hop described by p (spec / ybuf set) on the engine's stream, any supported window length
+int single_hop_forward(rc_engine *e, const rc::HopParams &p) {
+    if (e->log2n <= 14) {
+        RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, p, e->stream));
+        return RC_OK;
+    }
+    if (int rc = e->d_ysub.reserve((size_t)e->par.window_len * sizeof(float))) return rc;
+    rc::BigParams b = big_params(e, p);
+    b.ysub = (float2 *)e->d_ysub.p;
+    b.spec = p.spec;
+    b.ybuf = p.ybuf;
+    RC_HIP(rc::launch_big(0, b, e->stream));
+    RC_HIP(rc::launch_big(1, b, e->stream, rc::MODE_FORWARD));
+    return RC_OK;
+}
+int single_hop_resynth(rc_engine *e, const rc::HopParams &p) {
+    if (e->log2n <= 14) {
+        RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, p, e->stream));
+        return RC_OK;
+    }
+    if (int rc = e->d_ysub.reserve((size_t)e->par.window_len * sizeof(float))) return rc;
+    rc::BigParams b = big_params(e, p);
+    b.ysub = (float2 *)e->d_ysub.p;
+    b.spec = p.spec;
+    b.ybuf = p.ybuf;
+    RC_HIP(rc::launch_big(1, b, e->stream, rc::MODE_RESYNTH));
+    RC_HIP(rc::launch_big(2, b, e->stream));
     return RC_OK;
 }
 
@@ -497,8 +553,6 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) {
     const int log2n = ilog2_exact(cfg->window_len);
     if (log2n < 5 || log2n > 16)
         return fail(RC_EUNSUPPORTED, "window_len %u: the GPU path supports powers of two in [32, 65536]", cfg->window_len);
-    if (log2n > 14 && cfg->kernel)
-        return fail(RC_EUNSUPPORTED, "user frequency kernels are limited to window_len <= 16384 on the GPU path for now");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         (void)hipGetLastError();
@@ -616,6 +670,7 @@ void rc_engine_destroy(rc_engine *e) {
     e->d_out.release();
     e->d_spec.release();
     e->d_ybuf.release();
+    e->d_ysub.release();
     e->d_tail.release();
     e->d_hop_in.release();
     e->d_hop_out.release();
@@ -817,7 +872,6 @@ int rc_engine_last_kernel_stats(rc_engine *e, float *kernel_ms, uint64_t *hops, 
 
 int rc_engine_forward_fft(rc_engine *e, const float *samples, float *out_reim) {
     if (!e || !samples || !out_reim) return fail(RC_EINVAL, "null argument");
-    if (e->log2n > 14) return fail(RC_EUNSUPPORTED, "single-hop entry points are limited to window_len <= 16384");
     const uint32_t N = e->par.window_len;
     RC_HIP(hipSetDevice(e->device));
     int rc;
@@ -836,7 +890,7 @@ int rc_engine_forward_fft(rc_engine *e, const float *samples, float *out_reim) {
     p.run_len = 1;
     p.step = 1;
     p.spec = (float2 *)e->d_hop_out.p;
-    RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, p, e->stream));
+    if ((rc = single_hop_forward(e, p))) return rc;
     RC_HIP(hipMemcpyAsync(out_reim, e->d_hop_out.p, (size_t)N * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     RC_HIP(hipStreamSynchronize(e->stream));
     return RC_OK;
@@ -844,7 +898,6 @@ int rc_engine_forward_fft(rc_engine *e, const float *samples, float *out_reim) {
 
 int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float *samples, float *out) {
     if (!e || !samples || !out) return fail(RC_EINVAL, "null argument");
-    if (e->log2n > 14) return fail(RC_EUNSUPPORTED, "single-hop entry points are limited to window_len <= 16384");
     const uint32_t N = e->par.window_len;
     RC_HIP(hipSetDevice(e->device));
     int rc;
@@ -867,7 +920,7 @@ int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float 
     p.run_len = 1;
     p.spec = (float2 *)e->d_hop_out.p;
     p.ybuf = (float *)e->d_ybuf.p;
-    RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, p, e->stream));
+    if ((rc = single_hop_forward(e, p))) return rc;
     if (e->cfg.kernel) {
         e->h_spec.resize((size_t)N * 2);
         e->h_spec2.resize((size_t)N * 2);
@@ -876,7 +929,7 @@ int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float 
         if (e->cfg.kernel(now_ms(e), e->h_spec.data(), e->h_spec2.data(), N, e->cfg.kernel_user) == 0)
             RC_HIP(hipMemcpyAsync(e->d_hop_out.p, e->h_spec2.data(), (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
     }
-    RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, p, e->stream));
+    if ((rc = single_hop_resynth(e, p))) return rc;
     RC_HIP(hipMemcpyAsync(out, e->d_ybuf.p, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     RC_HIP(hipStreamSynchronize(e->stream));
     return RC_OK;

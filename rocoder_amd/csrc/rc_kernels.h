@@ -79,6 +79,7 @@ struct BigParams {
     const float2 *rtab;      // [Ms/2+1] exp(-2 pi i j / N)
     float2 *ysub;            // [n_channels][hop_count][4][Ms] scratch: Y_s, then U_s (natural order)
     float *ybuf;             // [n_channels][hop_count][N] windowed resynthesis y_k
+    float2 *spec;            // [n_channels][hop_count][N] natural-order spectrum (user-kernel path)
     uint32_t step;
     uint64_t seed_mixed;
     uint32_t ch_first;
@@ -97,6 +98,7 @@ hipError_t launch_hop(int log2n, HopMode mode, const HopParams &p, hipStream_t s
 // tail_only: just save y_{last}[H..] of the chunk as the carried tail (no output written)
 hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only = false);
 // stage 0 = A (forward quarter FFTs), 1 = B (radix-4 + middle + radix-4), 2 = C (inverse quarter FFTs)
-hipError_t launch_big(int stage, const BigParams &p, hipStream_t s);
+// mode selects stage B's variant (user-kernel path: MODE_FORWARD, host apply(), MODE_RESYNTH)
+hipError_t launch_big(int stage, const BigParams &p, hipStream_t s, HopMode mode = MODE_FUSED);
 
 }  // namespace rc

@@ -1516,6 +1516,9 @@ __device__ __forceinline__ void radix4(const float2 (&a)[4], float2 (&o)[4]) {
 }
 
 // Stage B: one thread per residue pair (k2, Ms - k2), k2 in [0, Ms/2].
+// MODE_FUSED: analysis + random phases + synthesis; MODE_FORWARD: analysis only, natural-order
+// spectrum to p.spec; MODE_RESYNTH: magnitudes from p.spec (after the user kernel), synthesis.
+template <int MODE>
 __global__ __launch_bounds__(256) void big_b_kernel(const BigParams p) {
     const uint32_t N = 1u << p.log2n, M = N / 2, Ms = M / 4;
     const uint32_t k2 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1524,10 +1527,12 @@ __global__ __launch_bounds__(256) void big_b_kernel(const BigParams p) {
     const uint32_t ch = blockIdx.z;
     const int64_t k = p.hop_first + hop_local;
     const uint32_t r = k2, rp = (Ms - k2) & (Ms - 1);
-    GV2W y = (GV2W)p.ysub + ((size_t)ch * p.hop_count + (size_t)hop_local) * 4 * (size_t)Ms;
+    const size_t hop_idx = (size_t)ch * p.hop_count + (size_t)hop_local;
+    GV2W y = (GV2W)p.ysub + hop_idx * 4 * (size_t)Ms;
+    GV2W spec = (GV2W)p.spec + hop_idx * (size_t)N;
     GV2 t1 = (GV2)p.t1;
     const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
-    float2 wr[4], wp[4], a[4], b[4], Zr[4], Zp[4], Vr[4], Vp[4];
+    float2 wr[4], wp[4], Zr[4], Zp[4], Vr[4], Vp[4];
     wr[0] = wp[0] = make_float2(1.f, 0.f);
     wr[1] = ldg2(t1 + r);
     wr[2] = ldg2(t1 + 2 * r);   // 2r <= Ms
@@ -1535,36 +1540,59 @@ __global__ __launch_bounds__(256) void big_b_kernel(const BigParams p) {
     wp[1] = ldg2(t1 + rp);
     wp[2] = cmul(wp[1], wp[1]);
     wp[3] = cmul(wp[1], wp[2]);
+    if constexpr (MODE != MODE_RESYNTH) {
+        float2 a[4], b[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        a[s] = cmul(wr[s], ldg2((GV2)y + (size_t)s * Ms + r));
-        b[s] = cmul(wp[s], ldg2((GV2)y + (size_t)s * Ms + rp));
+        for (int s = 0; s < 4; ++s) {
+            a[s] = cmul(wr[s], ldg2((GV2)y + (size_t)s * Ms + r));
+            b[s] = cmul(wp[s], ldg2((GV2)y + (size_t)s * Ms + rp));
+        }
+        radix4<-1>(a, Zr);  // Z[r + Ms k1]
+        radix4<-1>(b, Zp);  // Z[rp + Ms k1]
     }
-    radix4<-1>(a, Zr);  // Z[r + Ms k1]
-    radix4<-1>(b, Zp);  // Z[rp + Ms k1]
     const float2 wbase = ldg2((GV2)p.rtab + k2);  // exp(-2 pi i k2 / N)
     const float c8 = 0.70710678118654752f;
     const float2 e8[4] = {make_float2(1.f, 0.f), make_float2(c8, -c8), make_float2(0.f, -1.f),
                           make_float2(-c8, -c8)};  // exp(-2 pi i k1 / 8)
-    const float nkappa = -0.25f / (float)N;
 #pragma unroll
     for (int k1 = 0; k1 < 4; ++k1) {
         const uint32_t J = k2 + Ms * (uint32_t)k1;  // partner M - J
-        const float2 A = Zr[k1];
-        const float2 Bp = (k2 == 0) ? Zr[(4 - k1) & 3] : Zp[3 - k1];
         const float2 w = cmul(wbase, e8[k1]);
-        float2 X1, X2c;
-        pair_analyze(A, Bp, w, X1, X2c);
-        float m1 = cabs_fast(X1) * nkappa, m2 = cabs_fast(X2c) * nkappa;
+        float m1a, m1b, m2a, m2b;  // scaled magnitudes of bins J, N - J, M - J, M + J
+        if constexpr (MODE == MODE_RESYNTH) {
+            const float nk = -0.5f / (float)N;
+            m1a = cabs_fast(ldg2((GV2)spec + J)) * nk;
+            m1b = cabs_fast(ldg2((GV2)spec + ((N - J) & (N - 1)))) * nk;
+            m2a = cabs_fast(ldg2((GV2)spec + (M - J))) * nk;
+            m2b = cabs_fast(ldg2((GV2)spec + ((M + J) & (N - 1)))) * nk;
+        } else {
+            const float2 A = Zr[k1];
+            const float2 Bp = (k2 == 0) ? Zr[(4 - k1) & 3] : Zp[3 - k1];
+            float2 X1, X2c;
+            pair_analyze(A, Bp, w, X1, X2c);
+            if constexpr (MODE == MODE_FORWARD) {  // same stores as do_pair<.., MODE_FORWARD>
+                const float2 x1 = make_float2(0.5f * X1.x, 0.5f * X1.y);
+                const float2 x2 = make_float2(0.5f * X2c.x, 0.5f * X2c.y);
+                stg2(spec + J, x1);
+                stg2(spec + ((N - J) & (N - 1)), make_float2(x1.x, J ? -x1.y : x1.y));
+                stg2(spec + (M - J), make_float2(x2.x, -x2.y));
+                stg2(spec + ((M + J) & (N - 1)), J ? x2 : make_float2(x2.x, -x2.y));
+                continue;
+            }
+            const float nk = -0.25f / (float)N;
+            m1a = m1b = cabs_fast(X1) * nk;
+            m2a = m2b = cabs_fast(X2c) * nk;
+        }
         float c1, s1, c2, s2, c3, s3, c4, s4;
         phase_quad(key, J, M, c1, s1, c2, s2, c3, s3, c4, s4);
-        const float px = m1 * (c1 + c2), py = m1 * (s1 - s2);
-        const float qx = m2 * (c3 + c4), qy = m2 * (s4 - s3);
+        const float px = m1a * c1 + m1b * c2, py = m1a * s1 - m1b * s2;
+        const float qx = m2a * c3 + m2b * c4, qy = m2b * s4 - m2a * s3;
         const float sx = px + qx, sy = py + qy, rx = px - qx, ry = py - qy;
         const float ux = rx * w.x + ry * w.y, uy = ry * w.x - rx * w.y;
         Vr[k1] = make_float2(sx - uy, sy + ux);      // V[J]
         Vp[3 - k1] = make_float2(sx + uy, ux - sy);  // V[M - J] = V[rp + Ms (3 - k1)]   (k2 > 0)
     }
+    if constexpr (MODE == MODE_FORWARD) return;
     float2 u[4];
     radix4<+1>(Vr, u);
 #pragma unroll
@@ -1613,12 +1641,14 @@ hipError_t launch_hop(int log2n, HopMode mode, const HopParams &p, hipStream_t s
     }
 }
 
-hipError_t launch_big(int stage, const BigParams &p, hipStream_t s) {
+hipError_t launch_big(int stage, const BigParams &p, hipStream_t s, HopMode mode) {
     if (p.log2n != 15 && p.log2n != 16) return hipErrorInvalidValue;
     if (stage == 1) {
         const uint32_t Ms = (1u << p.log2n) / 8;
         const dim3 grid((Ms / 2 + 1 + 255) / 256, (unsigned)p.hop_count, p.n_channels), block(256);
-        hipLaunchKernelGGL(big_b_kernel, grid, block, 0, s, p);
+        if (mode == MODE_FORWARD) hipLaunchKernelGGL(big_b_kernel<MODE_FORWARD>, grid, block, 0, s, p);
+        else if (mode == MODE_RESYNTH) hipLaunchKernelGGL(big_b_kernel<MODE_RESYNTH>, grid, block, 0, s, p);
+        else hipLaunchKernelGGL(big_b_kernel<MODE_FUSED>, grid, block, 0, s, p);
         return hipGetLastError();
     }
     // quarter FFT of N/8 complex points == the passes of window length N/4
