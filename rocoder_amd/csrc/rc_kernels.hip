@@ -865,6 +865,7 @@ __device__ __forceinline__ GF hop_src(const HopParams &p, GF xc, GF xt, int64_t 
 #define RC_LDS_PAD 0  // diagnostic: extra dynamic LDS to force one workgroup per CU
 #endif
 constexpr int f1_idx(int n) { return n + (n >> 5); }
+constexpr int HOP2_LDS_FLOAT2 = 8192 + 256 + 32 + 8 + 32 + 256 + 256 + 16 + 24 + 1024;  // 79 232 B
 constexpr int f3_idx(int n) { return n + (n >> 5) + (n >> 8); }
 constexpr int brev_c(int x, int bits) {
     int r = 0;
@@ -899,9 +900,18 @@ __device__ __forceinline__ void vdit_rot(v2f a, v2f b, v2f w, v2f w2r, v2f &r, v
     o = __builtin_elementwise_fma(a, two, -r);
 }
 
+// wfine = W_{2^(S_HI+1)}^l, the base twiddle of the last stage; the base of stage s - 1 is the
+// square of the base of stage s (no table loads inside the hop loop: a global load waited on in
+// place costs its full latency, and vmcnt retires in order behind the output stores).
 template <int NREG, int M_LOG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L>
-__device__ __forceinline__ void dit_stages(v2f (&v)[NREG], int l, GV2 wtab) {
+__device__ __forceinline__ void dit_stages(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f}) {
     const v2f sgn = CONJ ? v2f{1.0f, -1.0f} : v2f{-1.0f, 1.0f};
+    v2f bases[S_HI - S_LO + 1];
+    if (HAS_L) {
+        bases[S_HI - S_LO] = wfine;
+#pragma unroll
+        for (int s = S_HI - 1; s >= S_LO; --s) bases[s - S_LO] = vcmul(bases[s + 1 - S_LO], bases[s + 1 - S_LO]);
+    }
 #pragma unroll
     for (int s = S_LO; s <= S_HI; ++s) {
         const int rb = s - REG_LO;
@@ -928,9 +938,7 @@ __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], int l, GV2 wtab) {
                 }
             }
         } else {
-            float2 bt = ldg2(wtab + (l << (M_LOG - 1 - s)));  // W_{2^(s+1)}^l
-            opaque(bt);
-            const v2f base = to_v(bt);
+            const v2f base = bases[s - S_LO];  // W_{2^(s+1)}^l
             // twiddles of the first half of the stage (c < half/2); the rest are these times -i
             constexpr int NCMAX = NREG / 4 > 0 ? NREG / 4 : 1;
             const int nc = half > 1 ? half / 2 : 1;
@@ -1031,6 +1039,14 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
     constexpr int LOG2N = 14, m = 13, M = 1 << m, H = M, T = 256, P = 32, PH = 16;
     constexpr int RES = 512;                      // residues of the last forward pass
     constexpr int SCR = f3_idx(M) + 8;            // 32-element scratch for thread 0's pairs
+    // per-workgroup twiddle / window-rotation tables (filled once per run): the hop loop itself has
+    // no table loads from global memory
+    constexpr int T_A = SCR + 32;                 // [256] W_8192^t
+    constexpr int T_R = T_A + 256;                // [256] W_16384^t
+    constexpr int T_B = T_R + 256;                // [16]  W_512^l
+    constexpr int T_C = T_B + 16;                 // [24]  W_64^k, k <= 16
+    constexpr int T_H = T_C + 24;                 // [1024] HANN: hann_rot as float2 pairs
+    static_assert(T_H + 1024 == HOP2_LDS_FLOAT2, "LDS layout");
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const uint32_t run = blockIdx.x % p.runs_per_channel;
@@ -1068,6 +1084,17 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
     if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(RC_PRIO);
 #endif
 
+    {
+        lds[T_A + tid] = ldg2(wtab + tid);
+        lds[T_R + tid] = ldg2((GV2)p.rtab + tid);
+        if (tid < 16) lds[T_B + tid] = ldg2(wtab + 16 * tid);
+        if (tid <= 16) lds[T_C + tid] = ldg2(wtab + 128 * tid);
+        if constexpr (HANN) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds[T_H + tid + 256 * i] = ldg2((GV2)p.hann_rot + tid + 256 * i);
+        }
+        __syncthreads();
+    }
     // HANN only (the table-window variant has no registers to spare): the next hop's raw input is
     // loaded RC_XPREFETCH stages ahead and stays in flight while this hop finishes
     constexpr bool XPF = HANN && RC_XPREFETCH != 0;
@@ -1093,10 +1120,8 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
                 }
             }
             if constexpr (HANN) {
-                GF rot = per_hop(p.hann_rot);
-                const float cb0 = (rot + 0)[4 * tid], sb0 = (rot + 0)[4 * tid + 1];
-                const float cb1 = (rot + 0)[4 * tid + 2], sb1 = (rot + 0)[4 * tid + 3];
-                __builtin_amdgcn_sched_barrier(0);
+                const float2 r0 = lds[T_H + 2 * tid], r1 = lds[T_H + 2 * tid + 1];
+                const float cb0 = r0.x, sb0 = r0.y, cb1 = r1.x, sb1 = r1.y;
 #pragma unroll
                 for (int q = 0; q < P; ++q) {
                     const float w0 = fmaf(HANN_W14.s[q], sb0, fmaf(HANN_W14.c[q], cb0, 0.5f));
@@ -1123,7 +1148,7 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         }
         st.mark(0);
         // ---- forward: F1 (bits 0..4, constants), E1, F2 (bits 5..8), E2, F3 (bits 9..12)
-        dit_stages<32, m, 0, 4, 0, false, false>(v, 0, wtab);
+        dit_stages<32, m, 0, 4, 0, false, false>(v);
         st.mark(1);
 #pragma unroll
         for (int q = 0; q < P; ++q) lds[bE1s + f3_idx(q)] = to_f2(v[q]);
@@ -1132,7 +1157,7 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         st.mark(3);
 #pragma unroll
         for (int q = 0; q < P; ++q) v[q] = to_v(lds[b4f3 + f3_idx(q << 4)]);
-        dit_stages<32, m, 5, 8, 4, false, true>(v, l4, wtab);
+        dit_stages<32, m, 5, 8, 4, false, true>(v, to_v(lds[T_B + l4]));
         st.mark(4);
         // E2 store is IN PLACE (same layout, same index map as the E1 load): each thread overwrites
         // exactly the elements it read, so no barrier is needed between the two
@@ -1150,8 +1175,15 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         st.mark(7);
         if (!(RC_ABLATE & 32)) __syncthreads();
         st.mark(8);
-        dit_stages<16, m, 9, 12, 9, false, true>(va, r, wtab);
-        dit_stages<16, m, 9, 12, 9, false, true>(vb, rb, wtab);
+        {
+            const v2f wa = to_v(lds[T_A + tid]);  // W_8192^r
+            // W_8192^rb: rb = 512 - r -> W_16 conj(W_8192^r); thread 0: rb = 256 -> W_32
+            const v2f k16 = {W32_RE[2], W32_IM[2]};
+            v2f wb = vcmul(v2f{wa.x, -wa.y}, k16);
+            if (tid == 0) wb = v2f{W32_RE[1], W32_IM[1]};
+            dit_stages<16, m, 9, 12, 9, false, true>(va, wa);
+            dit_stages<16, m, 9, 12, 9, false, true>(vb, wb);
+        }
         st.mark(9);
 
         // ---- middle stage in registers: pair (A[q], B[15-q]) = bins (r + 512 q, M - that)
@@ -1163,9 +1195,8 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
             }
         }
         {
-            int rr = r;
-            opaque(rr);
-            const float2 wr = ldg2((GV2)p.rtab + rr);          // exp(-2 pi i r / N), r < 512
+            const int rr = r;
+            const float2 wr = lds[T_R + tid];                  // exp(-2 pi i r / N), r = tid
             const uint32_t x0 = (uint32_t)rr * key.mul + key.k0;  // counter of bin r
             const uint32_t dx = (uint32_t)RES * key.mul;          // + 512 bins
 #pragma unroll
@@ -1189,7 +1220,7 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
                 else if (i == 8) { ja = RES * 8; ia = 8; ib = 8; }
                 else { ja = RES / 2 + RES * (i - 9); ia = 16 + (i - 9); ib = 16 + 15 - (i - 9); }
                 const float2 A = lds[SCR + ia], Bp = lds[SCR + ib];
-                const float2 w = ldg2(wtab + (ja >> 1));  // exp(-2 pi i ja / N) = W_M^(ja/2), ja even
+                const float2 w = lds[T_C + (ja >> 8)];  // exp(-2 pi i ja / N) = W_64^(ja/256)
                 float2 VA, VB;
                 pair_regs<LOG2N>(A, Bp, w, (uint32_t)ja * key.mul + key.k0, key, VA, VB, ja == 0);
                 lds[SCR + ia] = VA;
@@ -1211,8 +1242,8 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
             pa[brev_c(q, 4)] = va[q];
             pb[brev_c(q, 4)] = vb[q];
         }
-        dit_stages<16, m, 0, 3, 0, true, false>(pa, 0, wtab);
-        dit_stages<16, m, 0, 3, 0, true, false>(pb, 0, wtab);
+        dit_stages<16, m, 0, 3, 0, true, false>(pa);
+        dit_stages<16, m, 0, 3, 0, true, false>(pb);
         st.mark(12);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -1224,7 +1255,7 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         st.mark(14);
 #pragma unroll
         for (int q = 0; q < P; ++q) v[q] = to_v(lds[b4f3 + f3_idx(q << 4)]);
-        dit_stages<32, m, 4, 8, 4, true, true>(v, l4, wtab);
+        dit_stages<32, m, 4, 8, 4, true, true>(v, to_v(lds[T_B + l4]));
         st.mark(15);
 #pragma unroll
         for (int q = 0; q < P; ++q) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);  // in place (see E2)
@@ -1246,7 +1277,7 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        dit_stages<32, m, 9, 12, 8, true, true>(v, tid, wtab);
+        dit_stages<32, m, 9, 12, 8, true, true>(v, to_v(lds[T_A + tid]));
         if constexpr (XPF && RC_XPREFETCH == 1) {  // (the last hop re-reads itself)
             __builtin_amdgcn_sched_barrier(0);
             GF src = hop_src(p, xc, xt, k + 1 < k_end ? k + 1 : k);
@@ -1262,12 +1293,12 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         // ---- epilogue: synthesis window, overlap-add with the carried tail, store
         float rot[8];  // HANN: cos/sin beta of this thread's (window e=0, e=1, envelope e=0, e=1)
         if constexpr (HANN) {
-            GF rsrc = per_hop(p.hann_rot);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rot[i] = rsrc[4 * tid + i];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rot[4 + i] = (rsrc + 4 * T)[4 * tid + i];
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < 2; ++i) {
+                const float2 a = lds[T_H + 2 * tid + i], b = lds[T_H + 2 * T + 2 * tid + i];
+                rot[2 * i] = a.x, rot[2 * i + 1] = a.y;
+                rot[4 + 2 * i] = b.x, rot[4 + 2 * i + 1] = b.y;
+            }
 #pragma unroll
             for (int q = 0; q < P; ++q) {
                 v[q].x *= fmaf(HANN_W14.s[q], rot[1], fmaf(HANN_W14.c[q], rot[0], 0.5f));
@@ -1402,7 +1433,7 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
     switch (mode) {
         case MODE_FUSED:
             if (RC_V2 && LOG2N == 14) {
-                const size_t lds2 = sizeof(float2) * (size_t)(f3_idx(G::M) + 8 + 32) + RC_LDS_PAD;
+                const size_t lds2 = sizeof(float2) * (size_t)HOP2_LDS_FLOAT2 + RC_LDS_PAD;
                 const bool hann = p.hann_rot != nullptr;
                 if (p.pitch == 1 && hann) hipLaunchKernelGGL((hop2_kernel<true, true>), grid, block, lds2, s, p);
                 else if (p.pitch == 1) hipLaunchKernelGGL((hop2_kernel<true, false>), grid, block, lds2, s, p);
