@@ -193,6 +193,9 @@ void plan_runs(const rc_engine *e, uint32_t n_channels, int64_t hop_count, uint3
     const size_t lds_cap = 160 * 1024;
     uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(lds_cap / std::max<size_t>(lds, 1), 2048 / threads));
     wg_per_cu = std::min<uint32_t>(wg_per_cu, 8);
+#ifdef RC_WG_PER_CU
+    wg_per_cu = RC_WG_PER_CU;  // tuning builds
+#endif
     const uint64_t target = (uint64_t)e->n_cu * wg_per_cu * 2;  // 2 waves of workgroups
     uint64_t r = std::max<uint64_t>(1, target / std::max<uint32_t>(1, n_channels));
     const int64_t min_run = 8;

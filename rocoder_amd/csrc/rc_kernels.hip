@@ -163,6 +163,9 @@ __device__ __forceinline__ void opaque(int &x) { asm volatile("" : "+v"(x)); }
 #ifndef RC_XPREFETCH
 #define RC_XPREFETCH 1
 #endif
+#ifndef RC_SWP
+#define RC_SWP 1
+#endif
 struct Stamps {
 #if RC_STAMP
     unsigned long long last;
@@ -865,7 +868,18 @@ __device__ __forceinline__ GF hop_src(const HopParams &p, GF xc, GF xt, int64_t 
 #define RC_LDS_PAD 0  // diagnostic: extra dynamic LDS to force one workgroup per CU
 #endif
 constexpr int f1_idx(int n) { return n + (n >> 5); }
-constexpr int HOP2_LDS_FLOAT2 = 8192 + 256 + 32 + 8 + 32 + 256 + 256 + 16 + 24 + 1024;  // 79 232 B
+// RC_HALFEXP: TIMING-ONLY experiment (results are wrong): exchange addresses wrap into a half-size
+// buffer so that three workgroups fit one CU; RC_HALFEXP - 1 extra barriers per exchange
+#ifndef RC_HALFEXP
+#define RC_HALFEXP 0
+#endif
+constexpr int HOP2_XM = RC_HALFEXP ? 4095 : 8191;
+constexpr int HOP2_XBUF = RC_HALFEXP ? (4096 + 128 + 16) : (8192 + 256 + 32);
+constexpr int HOP2_LDS_FLOAT2 = HOP2_XBUF + 8 + 32 + 256 + 256 + 16 + 24 + 1024;  // 79 232 B
+__device__ __forceinline__ void xbar() {
+#pragma unroll
+    for (int i = 1; i < RC_HALFEXP; ++i) __syncthreads();
+}
 constexpr int f3_idx(int n) { return n + (n >> 5) + (n >> 8); }
 constexpr int brev_c(int x, int bits) {
     int r = 0;
@@ -903,8 +917,23 @@ __device__ __forceinline__ void vdit_rot(v2f a, v2f b, v2f w, v2f w2r, v2f &r, v
 // wfine = W_{2^(S_HI+1)}^l, the base twiddle of the last stage; the base of stage s - 1 is the
 // square of the base of stage s (no table loads inside the hop loop: a global load waited on in
 // place costs its full latency, and vmcnt retires in order behind the output stores).
+// Exchange read of one complex: ds_read_b64 moves 256 B/clk/CU, but the compiler's DS merge pass
+// would pair neighbours into ds_read2_b64 (128 B/clk/CU: MI355X_MICROARCH.md LDS table); a volatile
+// access is left alone.
+#ifndef RC_XLD_VOLATILE
+#define RC_XLD_VOLATILE 0  // measured: no gain (LDS reads are not the limiter), kept for A/B
+#endif
+__device__ __forceinline__ v2f xld(const float2 *lds, int idx) {
+#if RC_XLD_VOLATILE
+    typedef const volatile v2f __attribute__((address_space(3))) *LV2;
+    return *(LV2)(lds + idx);
+#else
+    return to_v(lds[idx]);
+#endif
+}
 template <int NREG, int M_LOG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L>
 __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f}) {
+    if (RC_ABLATE & 8) return;
     const v2f sgn = CONJ ? v2f{1.0f, -1.0f} : v2f{-1.0f, 1.0f};
     v2f bases[S_HI - S_LO + 1];
     if (HAS_L) {
@@ -990,6 +1019,51 @@ __device__ __forceinline__ void pair_regs(float2 A, float2 Bp, float2 w, uint32_
     VB = make_float2(sx + uy, ux - sy);
 }
 
+// The same pair in packed (re,im) arithmetic: 17 v_pk_* + 10 transcendental + the two hashes instead
+// of ~50 scalar VALU ops. A wave issues one VALU instruction per ~4.75 cycles whatever it is, so the
+// instruction count, not the flop count, sets the middle stage's time (profiles/r01e stamps).
+#ifndef RC_PAIR_PK
+#define RC_PAIR_PK 1
+#endif
+__device__ __forceinline__ void phase_cs2_x(uint32_t x, v2f &lo, v2f &up) {
+    float a, b, c, d;
+    phase_ncs2_x(x, a, b, c, d);
+    lo = v2f{a, b};
+    up = v2f{c, d};
+}
+template <int LOG2N>
+__device__ __forceinline__ void pair_regs_pk(v2f A, v2f Bp, v2f w, uint32_t x1, PhaseKey key, v2f &VA,
+                                             v2f &VB) {
+    constexpr uint32_t N = 1u << LOG2N, M = N / 2;
+    const uint32_t cM = M * key.mul + 2u * key.k0;
+    const float nkappa = -0.25f / (float)N;
+    const v2f cj = {1.0f, -1.0f}, jc = {-1.0f, 1.0f};
+    const v2f Bc = Bp * cj;                                    // conj(Bp)
+    const v2f E = A + Bc, D = A - Bc;                          // 2E, 2D
+    const v2f T = vcmul(D, w);                                 // T = w D
+    // U = (X1.x, X2c.x) = (ex + ty, ex - ty), V = (X1.y, X2c.y) = (ey - tx, ey + tx)
+    const v2f U = __builtin_shufflevector(E, E, 0, 0) + __builtin_shufflevector(T, T, 1, 1) * cj;
+    const v2f V = __builtin_shufflevector(E, E, 1, 1) + __builtin_shufflevector(T, T, 0, 0) * jc;
+    const v2f q2 = __builtin_elementwise_fma(V, V, U * U);     // (|X1|^2, |X2c|^2)
+    const v2f mm = v2f{__builtin_amdgcn_sqrtf(q2.x), __builtin_amdgcn_sqrtf(q2.y)} * v2f{nkappa, nkappa};
+    v2f cs1, cs2, cs3, cs4;
+    phase_cs2_x(x1, cs1, cs4);       // bins ja and M + ja
+    phase_cs2_x(cM - x1, cs3, cs2);  // bins M - ja and N - ja
+    const v2f P0 = cs1 + cs2 * cj;   // (c1 + c2, s1 - s2)
+    const v2f Q0 = cs4 + cs3 * cj;   // (c4 + c3, s4 - s3)
+    const v2f m1 = __builtin_shufflevector(mm, mm, 0, 0), m2 = __builtin_shufflevector(mm, mm, 1, 1);
+    const v2f Pz = P0 * m1;
+    const v2f S = __builtin_elementwise_fma(Q0, m2, Pz);
+    const v2f R = __builtin_elementwise_fma(Q0, -m2, Pz);
+    // Uc = conj(w) R = (rx wx + ry wy, ry wx - rx wy)
+    const v2f t0 = R * __builtin_shufflevector(w, w, 0, 0);
+    const v2f Uc = __builtin_elementwise_fma(__builtin_shufflevector(R, R, 1, 0),
+                                             __builtin_shufflevector(w, w, 1, 1) * cj, t0);
+    const v2f Us = __builtin_shufflevector(Uc, Uc, 1, 0);      // (uy, ux)
+    VA = S + Us * jc;                                          // (sx - uy, sy + ux)
+    VB = Us + S * cj;                                          // (sx + uy, ux - sy)
+}
+
 // ---- default-window fast path: windows::hanning (src/windows.rs:4-9) and the crossfade envelope
 // (src/crossfade.rs:4-10) are both 0.5 - c cos(2 pi i / (len - 1)). Thread t touches samples
 // i = 512 q + 2 t + e, so cos(alpha_q + beta_te) = cos alpha_q cos beta_te - sin alpha_q sin beta_te:
@@ -1035,10 +1109,10 @@ __device__ constexpr HannK HANN_W14 = make_hann_k(0.5, 16384, 32);
 __device__ constexpr HannK HANN_E14 = make_hann_k(HANN_ENV_AMP, 8192, 16);
 
 template <bool PITCH1, bool HANN>
-__global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
+__global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const HopParams p) {
     constexpr int LOG2N = 14, m = 13, M = 1 << m, H = M, T = 256, P = 32, PH = 16;
     constexpr int RES = 512;                      // residues of the last forward pass
-    constexpr int SCR = f3_idx(M) + 8;            // 32-element scratch for thread 0's pairs
+    constexpr int SCR = HOP2_XBUF + 8;            // 32-element scratch for thread 0's pairs
     // per-workgroup twiddle / window-rotation tables (filled once per run): the hop loop itself has
     // no table loads from global memory
     constexpr int T_A = SCR + 32;                 // [256] W_8192^t
@@ -1065,19 +1139,19 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
     // residues of this thread and per-thread LDS bases (thread part of every access pattern)
     const int r = tid, rb = tid ? RES - tid : RES / 2;
     const int l4 = tid & 15, uu = tid >> 4;
-    const int pos4 = (uu << 9) | l4;                                  // LOR = 4 layout, q = 0
-    const int bE1s = f3_idx((int)(__brev((unsigned)tid) >> 24) << 5);  // brev8(t) << 5
+    const int pos4 = ((uu << 9) | l4) & HOP2_XM;                                  // LOR = 4 layout, q = 0
+    const int bE1s = f3_idx(((int)(__brev((unsigned)tid) >> 24) << 5) & HOP2_XM);  // brev8(t) << 5
     const int b4f3 = f3_idx(pos4);
     const int bAr = f3_idx(r), bBr = f3_idx(rb);
-    const int bE3a = f3_idx((int)(__brev((unsigned)r) >> 23) << 4);    // brev9(r) << 4
-    const int bE3b = f3_idx((int)(__brev((unsigned)rb) >> 23) << 4);
+    const int bE3a = f3_idx(((int)(__brev((unsigned)r) >> 23) << 4) & HOP2_XM);    // brev9(r) << 4
+    const int bE3b = f3_idx(((int)(__brev((unsigned)rb) >> 23) << 4) & HOP2_XM);
     const int bE4l = f3_idx(tid);
 
     Stamps st;
     st.init();
-    float2 tail[PH];
+    v2f tail[PH];
 #pragma unroll
-    for (int q = 0; q < PH; ++q) tail[q] = make_float2(0.f, 0.f);
+    for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
 #if RC_PRIO
     // the two workgroups of a CU run the same code; a static priority split keeps them from
     // marching in lockstep (one computes while the other waits on LDS / memory)
@@ -1091,88 +1165,116 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         if (tid <= 16) lds[T_C + tid] = ldg2(wtab + 128 * tid);
         if constexpr (HANN) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lds[T_H + tid + 256 * i] = ldg2((GV2)p.hann_rot + tid + 256 * i);
+            for (int i = 0; i < 2; ++i) {  // (cos, sin) of e = 0, 1 -> (cos e0, cos e1), (sin e0, sin e1)
+                const float2 a = ldg2((GV2)p.hann_rot + 512 * i + 2 * tid);
+                const float2 b = ldg2((GV2)p.hann_rot + 512 * i + 2 * tid + 1);
+                lds[T_H + 512 * i + 2 * tid] = make_float2(a.x, b.x);
+                lds[T_H + 512 * i + 2 * tid + 1] = make_float2(a.y, b.y);
+            }
         }
         __syncthreads();
     }
-    // HANN only (the table-window variant has no registers to spare): the next hop's raw input is
-    // loaded RC_XPREFETCH stages ahead and stays in flight while this hop finishes
-    constexpr bool XPF = HANN && RC_XPREFETCH != 0;
+#if RC_STAGGER
+    {   // tuning builds: delay the workgroup in the odd wave slot once, so the two workgroups of a CU
+        // do not reach their LDS exchanges together
+        if (tid == 0) reinterpret_cast<unsigned *>(lds + SCR)[0] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+        __syncthreads();
+        const unsigned slot = reinterpret_cast<volatile unsigned *>(lds + SCR)[0];
+        __syncthreads();
+        if (slot & 1)
+            for (int i = 0; i < RC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+    // The hop loop is software-pipelined (RC_SWP): the LDS stores of an exchange drain for ~800
+    // cycles during which the wave would only wait at the barrier, so the next hop's window multiply
+    // and first pass F1 (registers only) run between the E3 store and its barrier; the next hop's
+    // samples are requested before I1. vn carries F1's output into the next iteration.
+    //   RC_SWP = 0: plain order (optionally with the raw-input prefetch RC_XPREFETCH, HANN only)
+    constexpr bool SWP = RC_SWP != 0 && HANN;  // (the table-window variant has no registers to spare)
+    constexpr bool XPF = !SWP && HANN && RC_XPREFETCH != 0;
     float xr0[P], xr1[P];
-    if constexpr (XPF) {
-        GF src = hop_src(p, xc, xt, k_begin > 0 ? k_begin - 1 : k_begin);
+    auto issue_x = [&](int64_t kk) {
+        GF src = hop_src(p, xc, xt, kk);
 #pragma unroll
         for (int q = 0; q < P; ++q) {
             xr0[q] = (src + 2 * T * q)[lane2];
             xr1[q] = (src + 2 * T * q)[lane2 + 1];
         }
-    }
-    for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
-        const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
-        v2f v[P];
-        {   // load in F1 order: register q holds z[brev5(q) * T + t] * window
-            if constexpr (!XPF) {
-                GF src = hop_src(p, xc, xt, k);
+    };
+    // register q of vn := z[brev5(q) * T + t] * window, then F1 (bits 0..4, constants only)
+    auto win_f1 = [&](v2f (&vn)[P]) {
+        if constexpr (HANN) {
+            const v2f cb = to_v(lds[T_H + 2 * tid]), sb = to_v(lds[T_H + 2 * tid + 1]);
+            const v2f half = {0.5f, 0.5f};
 #pragma unroll
-                for (int q = 0; q < P; ++q) {
-                    xr0[q] = (src + 2 * T * q)[lane2];
-                    xr1[q] = (src + 2 * T * q)[lane2 + 1];
-                }
+            for (int q = 0; q < P; ++q) {  // packed: 3 instructions per sample pair
+                const v2f wq = __builtin_elementwise_fma(v2f{HANN_W14.s[q], HANN_W14.s[q]}, sb,
+                               __builtin_elementwise_fma(v2f{HANN_W14.c[q], HANN_W14.c[q]}, cb, half));
+                vn[brev_c(q, 5)] = v2f{xr0[q], xr1[q]} * wq;
             }
-            if constexpr (HANN) {
-                const float2 r0 = lds[T_H + 2 * tid], r1 = lds[T_H + 2 * tid + 1];
-                const float cb0 = r0.x, sb0 = r0.y, cb1 = r1.x, sb1 = r1.y;
+        } else {
+            GF win = per_hop(p.window);
+            float wr0[P], wr1[P];
 #pragma unroll
-                for (int q = 0; q < P; ++q) {
-                    const float w0 = fmaf(HANN_W14.s[q], sb0, fmaf(HANN_W14.c[q], cb0, 0.5f));
-                    const float w1 = fmaf(HANN_W14.s[q], sb1, fmaf(HANN_W14.c[q], cb1, 0.5f));
-                    v[brev_c(q, 5)].x = xr0[q] * w0;
-                    v[brev_c(q, 5)].y = xr1[q] * w1;
-                }
-            } else {
-                GF win = per_hop(p.window);
-                float wr0[P], wr1[P];
-#pragma unroll
-                for (int q = 0; q < P; ++q) {
-                    wr0[q] = (win + 2 * T * q)[lane2];
-                    wr1[q] = (win + 2 * T * q)[lane2 + 1];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < P; ++q) {
-                    v[brev_c(q, 5)].x = xr0[q] * wr0[q];
-                    v[brev_c(q, 5)].y = xr1[q] * wr1[q];
-                }
+            for (int q = 0; q < P; ++q) {
+                wr0[q] = (win + 2 * T * q)[lane2];
+                wr1[q] = (win + 2 * T * q)[lane2 + 1];
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
-        st.mark(0);
-        // ---- forward: F1 (bits 0..4, constants), E1, F2 (bits 5..8), E2, F3 (bits 9..12)
-        dit_stages<32, m, 0, 4, 0, false, false>(v);
-        st.mark(1);
 #pragma unroll
-        for (int q = 0; q < P; ++q) lds[bE1s + f3_idx(q)] = to_f2(v[q]);
+            for (int q = 0; q < P; ++q) vn[brev_c(q, 5)] = v2f{xr0[q], xr1[q]} * v2f{wr0[q], wr1[q]};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        st.mark(0);
+        dit_stages<32, m, 0, 4, 0, false, false>(vn);
+        st.mark(1);
+    };
+    const int64_t k_first = k_begin > 0 ? k_begin - 1 : k_begin;
+    v2f vn[P];
+    if constexpr (XPF || SWP) issue_x(k_first);
+    if constexpr (SWP) win_f1(vn);
+    for (int64_t k = k_first; k < k_end; ++k) {
+        const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+        v2f v[P];
+        if constexpr (!SWP) {
+            if constexpr (!XPF) issue_x(k);
+            win_f1(vn);
+        }
+        // ---- forward: F1 (done), E1, F2 (bits 5..8), E2, F3 (bits 9..12)
+#pragma unroll
+        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 128))) lds[bE1s + f3_idx(q)] = to_f2(vn[q]);
+        if (RC_ABLATE & 4) {
+#pragma unroll
+            for (int q = 0; q < P; ++q) v[q] = vn[q];
+        }
         st.mark(2);
         if (!(RC_ABLATE & 32)) __syncthreads();
         st.mark(3);
 #pragma unroll
-        for (int q = 0; q < P; ++q) v[q] = to_v(lds[b4f3 + f3_idx(q << 4)]);
+        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 256))) v[q] = xld(lds, b4f3 + f3_idx(q << 4));
+        xbar();
         dit_stages<32, m, 5, 8, 4, false, true>(v, to_v(lds[T_B + l4]));
         st.mark(4);
         // E2 store is IN PLACE (same layout, same index map as the E1 load): each thread overwrites
         // exactly the elements it read, so no barrier is needed between the two
 #pragma unroll
-        for (int q = 0; q < P; ++q) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);
+        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 128))) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);
         st.mark(5);
         if (!(RC_ABLATE & 32)) __syncthreads();
         st.mark(6);
         v2f va[16], vb[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            va[q] = to_v(lds[bAr + f3_idx(RES * q)]);
-            vb[q] = to_v(lds[bBr + f3_idx(RES * q)]);
+            if (!(RC_ABLATE & (4 | 256))) {
+                va[q] = xld(lds, bAr + f3_idx((RES * q) & HOP2_XM));
+                vb[q] = xld(lds, bBr + f3_idx((RES * q) & HOP2_XM));
+            } else {
+                va[q] = v[q];
+                vb[q] = v[q + 16];
+            }
         }
         st.mark(7);
+        xbar();
         if (!(RC_ABLATE & 32)) __syncthreads();
         st.mark(8);
         {
@@ -1201,17 +1303,28 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
             const uint32_t dx = (uint32_t)RES * key.mul;          // + 512 bins
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
+                if (RC_ABLATE & 16) continue;
                 // exp(-2 pi i (r + 512 q) / N) = wr * W32^q
+#if RC_PAIR_PK
+                const v2f wrv = to_v(wr);
+                const v2f wq = q == 0 ? wrv : (q == 8 ? v2f{wr.y, -wr.x}
+                               : vcmul(wrv, v2f{W32_RE[q & 15], W32_IM[q & 15]}));
+                v2f VA, VB;
+                pair_regs_pk<LOG2N>(va[q], vb[15 - q], wq, x0 + (uint32_t)q * dx, key, VA, VB);
+                va[q] = VA;
+                vb[15 - q] = VB;
+#else
                 const float2 wq = q == 0 ? wr : (q == 8 ? make_float2(wr.y, -wr.x)
                                   : cmul(wr, make_float2(W32_RE[q & 15], W32_IM[q & 15])));
                 float2 VA, VB;
                 pair_regs<LOG2N>(to_f2(va[q]), to_f2(vb[15 - q]), wq, x0 + (uint32_t)q * dx, key, VA, VB);
                 va[q] = to_v(VA);
                 vb[15 - q] = to_v(VB);
+#endif
             }
         }
         st.mark(10);
-        if (tid < 64) {  // wave 0: lanes 0..16 compute thread 0's 17 pairs from the scratch
+        if (tid < 64 && !(RC_ABLATE & 64)) {  // wave 0: lanes 0..16 compute thread 0's 17 pairs from the scratch
             const int i = tid;
             if (i <= 16) {
                 int ja, ia, ib;
@@ -1235,6 +1348,7 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
             }
         }
         st.mark(11);
+        if constexpr (SWP) issue_x(k + 1 < k_end ? k + 1 : k);  // (the last hop re-reads itself)
         // ---- inverse: I1 in registers (position bits 0..3 = brev4 of the register index)
         v2f pa[16], pb[16];
 #pragma unroll
@@ -1247,63 +1361,53 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         st.mark(12);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            lds[bE3a + f3_idx(q)] = to_f2(pa[q]);
-            lds[bE3b + f3_idx(q)] = to_f2(pb[q]);
+            if (!(RC_ABLATE & (4 | 128))) lds[bE3a + f3_idx(q)] = to_f2(pa[q]);
+            if (!(RC_ABLATE & (4 | 128))) lds[bE3b + f3_idx(q)] = to_f2(pb[q]);
         }
         st.mark(13);
+        if constexpr (SWP) win_f1(vn);  // next hop's window + F1 while the E3 stores drain
         if (!(RC_ABLATE & 32)) __syncthreads();
         st.mark(14);
 #pragma unroll
-        for (int q = 0; q < P; ++q) v[q] = to_v(lds[b4f3 + f3_idx(q << 4)]);
+        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 256))) v[q] = xld(lds, b4f3 + f3_idx(q << 4));
+        xbar();
         dit_stages<32, m, 4, 8, 4, true, true>(v, to_v(lds[T_B + l4]));
         st.mark(15);
 #pragma unroll
-        for (int q = 0; q < P; ++q) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);  // in place (see E2)
+        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 128))) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);  // in place (see E2)
         st.mark(16);
         if (!(RC_ABLATE & 32)) __syncthreads();
         st.mark(17);
 #pragma unroll
-        for (int q = 0; q < P; ++q) v[q] = to_v(lds[bE4l + f3_idx(q << 8)]);
+        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 256))) v[q] = xld(lds, bE4l + f3_idx((q << 8) & HOP2_XM));
         st.mark(18);
+        xbar();
         if (!(RC_ABLATE & 32)) __syncthreads();
         st.mark(19);
         if constexpr (XPF && RC_XPREFETCH == 2) {  // (the last hop re-reads itself)
             __builtin_amdgcn_sched_barrier(0);
-            GF src = hop_src(p, xc, xt, k + 1 < k_end ? k + 1 : k);
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                xr0[q] = (src + 2 * T * q)[lane2];
-                xr1[q] = (src + 2 * T * q)[lane2 + 1];
-            }
+            issue_x(k + 1 < k_end ? k + 1 : k);
             __builtin_amdgcn_sched_barrier(0);
         }
         dit_stages<32, m, 9, 12, 8, true, true>(v, to_v(lds[T_A + tid]));
         if constexpr (XPF && RC_XPREFETCH == 1) {  // (the last hop re-reads itself)
             __builtin_amdgcn_sched_barrier(0);
-            GF src = hop_src(p, xc, xt, k + 1 < k_end ? k + 1 : k);
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                xr0[q] = (src + 2 * T * q)[lane2];
-                xr1[q] = (src + 2 * T * q)[lane2 + 1];
-            }
+            issue_x(k + 1 < k_end ? k + 1 : k);
             __builtin_amdgcn_sched_barrier(0);
         }
         st.mark(20);
 
         // ---- epilogue: synthesis window, overlap-add with the carried tail, store
-        float rot[8];  // HANN: cos/sin beta of this thread's (window e=0, e=1, envelope e=0, e=1)
+        // HANN: (cos, cos) / (sin, sin) of this thread's beta for samples e = 0, 1 (window, envelope)
+        v2f cbW = {0.f, 0.f}, sbW = cbW, cbE = cbW, sbE = cbW;
+        const v2f half2 = {0.5f, 0.5f};
         if constexpr (HANN) {
+            cbW = to_v(lds[T_H + 2 * tid]), sbW = to_v(lds[T_H + 2 * tid + 1]);
+            cbE = to_v(lds[T_H + 2 * T + 2 * tid]), sbE = to_v(lds[T_H + 2 * T + 2 * tid + 1]);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const float2 a = lds[T_H + 2 * tid + i], b = lds[T_H + 2 * T + 2 * tid + i];
-                rot[2 * i] = a.x, rot[2 * i + 1] = a.y;
-                rot[4 + 2 * i] = b.x, rot[4 + 2 * i + 1] = b.y;
-            }
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                v[q].x *= fmaf(HANN_W14.s[q], rot[1], fmaf(HANN_W14.c[q], rot[0], 0.5f));
-                v[q].y *= fmaf(HANN_W14.s[q], rot[3], fmaf(HANN_W14.c[q], rot[2], 0.5f));
-            }
+            for (int q = 0; q < P; ++q)
+                v[q] *= __builtin_elementwise_fma(v2f{HANN_W14.s[q], HANN_W14.s[q]}, sbW,
+                        __builtin_elementwise_fma(v2f{HANN_W14.c[q], HANN_W14.c[q]}, cbW, half2));
             __builtin_amdgcn_sched_barrier(0);
         } else {
             GF wsrc = per_hop(p.window);
@@ -1315,10 +1419,7 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < P; ++q) {
-                v[q].x *= wr0[q];
-                v[q].y *= wr1[q];
-            }
+            for (int q = 0; q < P; ++q) v[q] *= v2f{wr0[q], wr1[q]};
             __builtin_amdgcn_sched_barrier(0);
         }
         if (k >= k_begin) {
@@ -1335,16 +1436,18 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                const v2f amp2 = {p.amp, p.amp};
 #pragma unroll
                 for (int q = 0; q < PH; ++q) {
-                    if constexpr (HANN) {
-                        er0[q] = fmaf(HANN_E14.s[q], rot[5], fmaf(HANN_E14.c[q], rot[4], 0.5f));
-                        er1[q] = fmaf(HANN_E14.s[q], rot[7], fmaf(HANN_E14.c[q], rot[6], 0.5f));
-                    }
-                    float2 o;  // stretcher.rs:97-100 operation order
-                    o.x = (v[q].x + tail[q].x) * er0[q] * p.amp;
-                    o.y = (v[q].y + tail[q].y) * er1[q] * p.amp;
-                    stg2((GV2W)(dst + 2 * T * q + lane2), o);
+                    v2f er;
+                    if constexpr (HANN)
+                        er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
+                             __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, half2));
+                    else
+                        er = v2f{er0[q], er1[q]};
+                    // stretcher.rs:97-100 operation order, both samples of the pair per instruction
+                    const v2f o = (v[q] + tail[q]) * er * amp2;
+                    *(GV2W)(dst + 2 * T * q + lane2) = o;
                 }
             } else {
                 const int64_t kq = g0 / pitch;
@@ -1355,16 +1458,14 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
 #pragma unroll
                 for (int q = 0; q < PH; ++q) {
                     const uint32_t i0 = 2u * (uint32_t)(t2 + T * q);
-                    float e0, e1;
-                    if constexpr (HANN) {
-                        e0 = fmaf(HANN_E14.s[q], rot[5], fmaf(HANN_E14.c[q], rot[4], 0.5f));
-                        e1 = fmaf(HANN_E14.s[q], rot[7], fmaf(HANN_E14.c[q], rot[6], 0.5f));
-                    } else {
-                        e0 = (esrc + 2 * T * q)[lane2];
-                        e1 = (esrc + 2 * T * q)[lane2 + 1];
-                    }
-                    const float o0 = (v[q].x + tail[q].x) * e0 * p.amp;
-                    const float o1 = (v[q].y + tail[q].y) * e1 * p.amp;
+                    v2f er;
+                    if constexpr (HANN)
+                        er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
+                             __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, half2));
+                    else
+                        er = v2f{(esrc + 2 * T * q)[lane2], (esrc + 2 * T * q)[lane2 + 1]};
+                    const v2f o = (v[q] + tail[q]) * er * v2f{p.amp, p.amp};
+                    const float o0 = o.x, o1 = o.y;
                     const uint32_t a0 = kr + i0, a1 = a0 + 1;
                     const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
                     if (d0 * pitch == a0) dst[d0] = o0;
@@ -1373,7 +1474,7 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
             }
         }
 #pragma unroll
-        for (int q = 0; q < PH; ++q) tail[q] = to_f2(v[q + PH]);
+        for (int q = 0; q < PH; ++q) tail[q] = v[q + PH];
         st.mark(21);
     }
 #if RC_STAMP
