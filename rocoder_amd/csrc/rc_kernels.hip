@@ -164,7 +164,7 @@ __device__ __forceinline__ void opaque(int &x) { asm volatile("" : "+v"(x)); }
 #define RC_XPREFETCH 1
 #endif
 #ifndef RC_SWP
-#define RC_SWP 1
+#define RC_SWP 2
 #endif
 struct Stamps {
 #if RC_STAMP
@@ -1229,7 +1229,92 @@ __global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const Hop
         dit_stages<32, m, 0, 4, 0, false, false>(vn);
         st.mark(1);
     };
+    // epilogue of hop kk (ve = its I3 output): synthesis window, overlap-add with the carried tail,
+    // store. With RC_SWP >= 2 it runs one iteration late, under the next hop's E1 store drain.
+    auto epilogue = [&](int64_t kk, v2f (&ve)[P]) {
+        // ---- epilogue: synthesis window, overlap-add with the carried tail, store
+        // HANN: (cos, cos) / (sin, sin) of this thread's beta for samples e = 0, 1 (window, envelope)
+        v2f cbW = {0.f, 0.f}, sbW = cbW, cbE = cbW, sbE = cbW;
+        const v2f half2 = {0.5f, 0.5f};
+        if constexpr (HANN) {
+            cbW = to_v(lds[T_H + 2 * tid]), sbW = to_v(lds[T_H + 2 * tid + 1]);
+            cbE = to_v(lds[T_H + 2 * T + 2 * tid]), sbE = to_v(lds[T_H + 2 * T + 2 * tid + 1]);
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+                ve[q] *= __builtin_elementwise_fma(v2f{HANN_W14.s[q], HANN_W14.s[q]}, sbW,
+                        __builtin_elementwise_fma(v2f{HANN_W14.c[q], HANN_W14.c[q]}, cbW, half2));
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            GF wsrc = per_hop(p.window);
+            float wr0[P], wr1[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                wr0[q] = (wsrc + 2 * T * q)[lane2];
+                wr1[q] = (wsrc + 2 * T * q)[lane2 + 1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < P; ++q) ve[q] *= v2f{wr0[q], wr1[q]};
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kk >= k_begin) {
+            const int64_t g0 = kk * (int64_t)H;
+            GF esrc = per_hop(p.env);
+            if constexpr (PITCH1) {
+                GFW dst = outc + (g0 - p.out_origin);
+                float er0[PH], er1[PH];
+                if constexpr (!HANN) {
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) {
+                        er0[q] = (esrc + 2 * T * q)[lane2];
+                        er1[q] = (esrc + 2 * T * q)[lane2 + 1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const v2f amp2 = {p.amp, p.amp};
+#pragma unroll
+                for (int q = 0; q < PH; ++q) {
+                    v2f er;
+                    if constexpr (HANN)
+                        er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
+                             __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, half2));
+                    else
+                        er = v2f{er0[q], er1[q]};
+                    // stretcher.rs:97-100 operation order, both samples of the pair per instruction
+                    const v2f o = (ve[q] + tail[q]) * er * amp2;
+                    *(GV2W)(dst + 2 * T * q + lane2) = o;
+                }
+            } else {
+                const int64_t kq = g0 / pitch;
+                const uint32_t kr = (uint32_t)(g0 % pitch);
+                GFW dst = outc + (kq - p.out_origin);
+                int t2 = tid;
+                opaque(t2);
+#pragma unroll
+                for (int q = 0; q < PH; ++q) {
+                    const uint32_t i0 = 2u * (uint32_t)(t2 + T * q);
+                    v2f er;
+                    if constexpr (HANN)
+                        er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
+                             __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, half2));
+                    else
+                        er = v2f{(esrc + 2 * T * q)[lane2], (esrc + 2 * T * q)[lane2 + 1]};
+                    const v2f o = (ve[q] + tail[q]) * er * v2f{p.amp, p.amp};
+                    const float o0 = o.x, o1 = o.y;
+                    const uint32_t a0 = kr + i0, a1 = a0 + 1;
+                    const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
+                    if (d0 * pitch == a0) dst[d0] = o0;
+                    if (d1 * pitch == a1) dst[d1] = o1;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PH; ++q) tail[q] = ve[q + PH];
+        st.mark(21);
+    };
     const int64_t k_first = k_begin > 0 ? k_begin - 1 : k_begin;
+    constexpr bool SWP2 = SWP && RC_SWP >= 2;
+    v2f vo[P];  // SWP2: I3 output of the previous hop, its epilogue still to run
     v2f vn[P];
     if constexpr (XPF || SWP) issue_x(k_first);
     if constexpr (SWP) win_f1(vn);
@@ -1246,6 +1331,9 @@ __global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const Hop
         if (RC_ABLATE & 4) {
 #pragma unroll
             for (int q = 0; q < P; ++q) v[q] = vn[q];
+        }
+        if constexpr (SWP2) {
+            if (k > k_first) epilogue(k - 1, vo);
         }
         st.mark(2);
         if (!(RC_ABLATE & 32)) __syncthreads();
@@ -1397,86 +1485,14 @@ __global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const Hop
         }
         st.mark(20);
 
-        // ---- epilogue: synthesis window, overlap-add with the carried tail, store
-        // HANN: (cos, cos) / (sin, sin) of this thread's beta for samples e = 0, 1 (window, envelope)
-        v2f cbW = {0.f, 0.f}, sbW = cbW, cbE = cbW, sbE = cbW;
-        const v2f half2 = {0.5f, 0.5f};
-        if constexpr (HANN) {
-            cbW = to_v(lds[T_H + 2 * tid]), sbW = to_v(lds[T_H + 2 * tid + 1]);
-            cbE = to_v(lds[T_H + 2 * T + 2 * tid]), sbE = to_v(lds[T_H + 2 * T + 2 * tid + 1]);
+        if constexpr (SWP2) {
 #pragma unroll
-            for (int q = 0; q < P; ++q)
-                v[q] *= __builtin_elementwise_fma(v2f{HANN_W14.s[q], HANN_W14.s[q]}, sbW,
-                        __builtin_elementwise_fma(v2f{HANN_W14.c[q], HANN_W14.c[q]}, cbW, half2));
-            __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < P; ++q) vo[q] = v[q];
         } else {
-            GF wsrc = per_hop(p.window);
-            float wr0[P], wr1[P];
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                wr0[q] = (wsrc + 2 * T * q)[lane2];
-                wr1[q] = (wsrc + 2 * T * q)[lane2 + 1];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < P; ++q) v[q] *= v2f{wr0[q], wr1[q]};
-            __builtin_amdgcn_sched_barrier(0);
+            epilogue(k, v);
         }
-        if (k >= k_begin) {
-            const int64_t g0 = k * (int64_t)H;
-            GF esrc = per_hop(p.env);
-            if constexpr (PITCH1) {
-                GFW dst = outc + (g0 - p.out_origin);
-                float er0[PH], er1[PH];
-                if constexpr (!HANN) {
-#pragma unroll
-                    for (int q = 0; q < PH; ++q) {
-                        er0[q] = (esrc + 2 * T * q)[lane2];
-                        er1[q] = (esrc + 2 * T * q)[lane2 + 1];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                const v2f amp2 = {p.amp, p.amp};
-#pragma unroll
-                for (int q = 0; q < PH; ++q) {
-                    v2f er;
-                    if constexpr (HANN)
-                        er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
-                             __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, half2));
-                    else
-                        er = v2f{er0[q], er1[q]};
-                    // stretcher.rs:97-100 operation order, both samples of the pair per instruction
-                    const v2f o = (v[q] + tail[q]) * er * amp2;
-                    *(GV2W)(dst + 2 * T * q + lane2) = o;
-                }
-            } else {
-                const int64_t kq = g0 / pitch;
-                const uint32_t kr = (uint32_t)(g0 % pitch);
-                GFW dst = outc + (kq - p.out_origin);
-                int t2 = tid;
-                opaque(t2);
-#pragma unroll
-                for (int q = 0; q < PH; ++q) {
-                    const uint32_t i0 = 2u * (uint32_t)(t2 + T * q);
-                    v2f er;
-                    if constexpr (HANN)
-                        er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
-                             __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, half2));
-                    else
-                        er = v2f{(esrc + 2 * T * q)[lane2], (esrc + 2 * T * q)[lane2 + 1]};
-                    const v2f o = (v[q] + tail[q]) * er * v2f{p.amp, p.amp};
-                    const float o0 = o.x, o1 = o.y;
-                    const uint32_t a0 = kr + i0, a1 = a0 + 1;
-                    const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
-                    if (d0 * pitch == a0) dst[d0] = o0;
-                    if (d1 * pitch == a1) dst[d1] = o1;
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < PH; ++q) tail[q] = v[q + PH];
-        st.mark(21);
     }
+    if constexpr (SWP2) epilogue(k_end - 1, vo);
 #if RC_STAMP
     if ((tid & 63) == 0 && p.spec) {
         unsigned *dbg = (unsigned *)p.spec + ((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * 32;
