@@ -931,6 +931,30 @@ __device__ __forceinline__ v2f xld(const float2 *lds, int idx) {
     return to_v(lds[idx]);
 #endif
 }
+// Runtime-twiddle butterflies with the (-w.y, w.y) / (w.x, -w.x) operand expressed as VOP3P source
+// modifiers (op_sel + neg_lo / neg_hi): hipcc does not fold a per-lane negation into the modifiers, so
+// the plain-C++ form needs one v_pk_mul per twiddle and form (124 per hop) to build those operands.
+#ifndef RC_ASMNEG
+#define RC_ASMNEG 1
+#endif
+//   r = a + w b (CONJ: a + conj(w) b), o = 2a - r
+template <bool CONJ>
+__device__ __forceinline__ void vdit_m(v2f a, v2f b, v2f w, v2f &r, v2f &o) {
+    const v2f t = __builtin_elementwise_fma(b, __builtin_shufflevector(w, w, 0, 0), a);
+    if (CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(b), "v"(w), "v"(t));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(b), "v"(w), "v"(t));
+    const v2f two = {2.0f, 2.0f};
+    o = __builtin_elementwise_fma(a, two, -r);
+}
+//   the same with the twiddle -i w (CONJ: +i conj(w))
+template <bool CONJ>
+__device__ __forceinline__ void vdit_rot_m(v2f a, v2f b, v2f w, v2f &r, v2f &o) {
+    const v2f t = __builtin_elementwise_fma(b, __builtin_shufflevector(w, w, 1, 1), a);
+    if (CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(b), "v"(w), "v"(t));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(b), "v"(w), "v"(t));
+    const v2f two = {2.0f, 2.0f};
+    o = __builtin_elementwise_fma(a, two, -r);
+}
 template <int NREG, int M_LOG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L>
 __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f}) {
     if (RC_ABLATE & 8) return;
@@ -978,8 +1002,10 @@ __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], v2f wfine = v2f{1.0f,
                 const int kidx = c * (16 >> rb);
                 const v2f kc = {W32_RE[kidx & 15], W32_IM[kidx & 15]};
                 tw[c] = c == 0 ? base : vcmul(base, kc);
-                tw2[c] = __builtin_shufflevector(tw[c], tw[c], 1, 1) * sgn;
-                twr[c] = __builtin_shufflevector(tw[c], tw[c], 0, 0) * (-sgn);
+                if (!RC_ASMNEG) {
+                    tw2[c] = __builtin_shufflevector(tw[c], tw[c], 1, 1) * sgn;
+                    twr[c] = __builtin_shufflevector(tw[c], tw[c], 0, 0) * (-sgn);
+                }
             }
 #pragma unroll
             for (int q0 = 0; q0 < NREG; ++q0) {
@@ -987,8 +1013,13 @@ __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], v2f wfine = v2f{1.0f,
                 const int q1 = q0 | half;
                 const int c = q0 & (half - 1);
                 const v2f a = v[q0], b = v[q1];
-                if (c < nc) vdit(a, b, tw[c], tw2[c], v[q0], v[q1]);
-                else vdit_rot(a, b, tw[c - nc], twr[c - nc], v[q0], v[q1]);
+                if (RC_ASMNEG) {
+                    if (c < nc) vdit_m<CONJ>(a, b, tw[c], v[q0], v[q1]);
+                    else vdit_rot_m<CONJ>(a, b, tw[c - nc], v[q0], v[q1]);
+                } else {
+                    if (c < nc) vdit(a, b, tw[c], tw2[c], v[q0], v[q1]);
+                    else vdit_rot(a, b, tw[c - nc], twr[c - nc], v[q0], v[q1]);
+                }
             }
         }
     }
