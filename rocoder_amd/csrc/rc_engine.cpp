@@ -185,6 +185,9 @@ uint64_t now_ms(const rc_engine *e) {
 
 // Split hop_count hops per channel into runs so the launch fills the chip (>= ~2 workgroups
 // of 256 threads per CU) while keeping the one-hop recompute overhead of each run small.
+#ifndef RC_ROUNDS
+#define RC_ROUNDS 2
+#endif
 void plan_runs(const rc_engine *e, uint32_t n_channels, int64_t hop_count, uint32_t *runs,
                uint32_t *run_len) {
     int threads = 64;
@@ -193,10 +196,15 @@ void plan_runs(const rc_engine *e, uint32_t n_channels, int64_t hop_count, uint3
     const size_t lds_cap = 160 * 1024;
     uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(lds_cap / std::max<size_t>(lds, 1), 2048 / threads));
     wg_per_cu = std::min<uint32_t>(wg_per_cu, 8);
+    uint32_t rounds = RC_ROUNDS;
+    if (const int fixed = rc::hop_workgroups_per_cu(e->log2n, e->d_hann_rot != nullptr)) {
+        wg_per_cu = (uint32_t)fixed;
+        rounds = 2 * RC_ROUNDS;  // measured: 4 rounds of 768 workgroups beat 2 (tail balance) and 6
+    }
 #ifdef RC_WG_PER_CU
     wg_per_cu = RC_WG_PER_CU;  // tuning builds
 #endif
-    const uint64_t target = (uint64_t)e->n_cu * wg_per_cu * 2;  // 2 waves of workgroups
+    const uint64_t target = (uint64_t)e->n_cu * wg_per_cu * rounds;  // rounds of resident workgroups
     uint64_t r = std::max<uint64_t>(1, target / std::max<uint32_t>(1, n_channels));
     const int64_t min_run = 8;
     r = std::min<uint64_t>(r, (uint64_t)std::max<int64_t>(1, hop_count / min_run));

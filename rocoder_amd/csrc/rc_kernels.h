@@ -93,6 +93,9 @@ enum HopMode { MODE_FUSED = 0, MODE_FORWARD = 1, MODE_RESYNTH = 2 };
 
 // Geometry chosen by the kernels for a window length (threads per workgroup, LDS bytes).
 bool hop_geometry(int log2n, int *threads, size_t *lds_bytes);
+// Workgroups of the fused kernel that share a CU when the kernel variant fixes it (0: derive it
+// from hop_geometry's LDS size). The run planner sizes a launch to two rounds of them.
+int hop_workgroups_per_cu(int log2n, bool default_window);
 // Launchers. Return hipSuccess or the launch error. log2n in [5, 14].
 hipError_t launch_hop(int log2n, HopMode mode, const HopParams &p, hipStream_t s);
 // tail_only: just save y_{last}[H..] of the chunk as the carried tail (no output written)
