@@ -8,7 +8,7 @@ samples per channel (600 s), i.e. 51 652 hops -> 423 133 184 output samples per 
 stereo job; channels/hop ranges are independent, there is no data-path collective).
 
 The same JSON line carries
-  roofline     — the dominant kernel (rc::hop2_kernel, the N=16384 fused hop kernel) priced on SURVEY §8(d4)'s
+  roofline     — the dominant kernel (rc::hop3_kernel, the N=16384 fused hop kernel) priced on SURVEY §8(d4)'s
                  algorithmic READ bytes 4*N per hop against the 8 TB/s HBM peak, its launch duration
                  measured live with events on the stream it is launched on;
   cpu_baseline — the CPU restatement of the reference algorithm (oracle/rocoder_oracle.c, "port":
@@ -200,12 +200,13 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel": "rc::hop2_kernel<pitch1> (N=16384 fused hop kernel)",
+                "kernel": "rc::hop3_kernel<pitch1> (N=16384 fused hop kernel, 3 workgroups/CU)",
                 "kernel_ms": round(kernel_ms, 4),
                 "hops_per_s": round(hops_per_step / (kernel_ms * 1e-3), 1),
                 "algorithmic_bytes_per_launch": algo_bytes,
-                "note": "algorithmic READ bytes 4*N per hop (SURVEY §8 d4); the kernel is VALU/LDS-bound "
-                        "(FFT butterflies + per-bin hash/sincos), see DESIGN.md",
+                "note": "algorithmic READ bytes 4*N per hop (SURVEY §8 d4); the kernel is VALU-pipe bound "
+                        "(FFT butterflies + per-bin hash/sincos: VALU busy 77 %) with LDS-exchange "
+                        "synchronisation on top, see DESIGN.md §5",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
