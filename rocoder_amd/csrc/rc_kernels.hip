@@ -1885,6 +1885,27 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
 //   Z[r + Ms k1] = sum_s W_M^{s r} (-i)^{s k1} Y_s[r],  Y_s = FFT_Ms(z_s)          (forward)
 //   y[4n'+s]     = IFFT_Ms(U_s)[n'],  U_s[r] = conj(W_M^{s r}) sum_k1 (+i)^{s k1} V[r + Ms k1]
 // Stage A/C reuse the in-LDS passes of the fused kernel on one quarter; stage B is per-bin.
+// The last forward pass leaves thread t with the bins brev(t) + T * brev5(q): written straight to
+// global memory that is 8 B per lane at a 32-B stride. Thread t therefore takes over, through LDS, the
+// 32 registers of thread brev(t) and stores bins t + T * brev5(q): 512 contiguous bytes per wave
+// instruction (big_c mirrors it for its loads). Row r of the LDS image starts at (r & 31) + 33 (r >> 5)
+// and register q adds 33 T / 32 * q: conflict-free 16-lane stores of row t and 32-lane loads of
+// row brev(t).
+template <class G>
+__device__ __forceinline__ int big_row(int r) { return (r & 31) + 33 * (r >> 5); }
+template <class G>
+__device__ __forceinline__ int big_brev_tid(int t) {
+    return (int)(__brev((unsigned)t) >> (32 - clog2(G::T)));
+}
+// blocks b and b + 8 share an XCD (MI355X_MICROARCH.md, workgroup dispatch): the four quarter
+// transforms of one hop are mapped to one XCD so that their interleaved 8-byte accesses to the hop's
+// samples meet in one L2. grid.x = 32 * ceil(hop_count / 8).
+__device__ __forceinline__ void big_block(uint32_t b, uint32_t &sub, int64_t &hop_local) {
+    const uint32_t g = b >> 5, r = b & 31u;
+    sub = r >> 3;
+    hop_local = (int64_t)g * 8 + (r & 7u);
+}
+
 template <int LOG2NS>  // Geo<LOG2NS>::M == Ms
 __global__ __launch_bounds__(Geo<LOG2NS>::T, 2) void big_a_kernel(const BigParams p) {
     using G = Geo<LOG2NS>;
@@ -1895,8 +1916,10 @@ __global__ __launch_bounds__(Geo<LOG2NS>::T, 2) void big_a_kernel(const BigParam
     ctx.tid = threadIdx.x;
     fill_lds_bases<G, G::m>(ctx);
     const int tid = ctx.tid;
-    const uint32_t sub = blockIdx.x & 3u;
-    const int64_t hop_local = blockIdx.x >> 2;
+    uint32_t sub;
+    int64_t hop_local;
+    big_block(blockIdx.x, sub, hop_local);
+    if (hop_local >= p.hop_count) return;
     const uint32_t ch = blockIdx.y;
     const int64_t k = p.hop_first + hop_local;
     GF xc = (GF)p.x + (size_t)ch * p.in_stride;
@@ -1914,11 +1937,17 @@ __global__ __launch_bounds__(Geo<LOG2NS>::T, 2) void big_a_kernel(const BigParam
     st.init();
     forward_passes<G, G::m, 0, true>(v, lds, ctx, (GV2)p.wtab_sub, st);
     GV2W y = (GV2W)p.ysub + (((size_t)ch * p.hop_count + (size_t)hop_local) * 4 + sub) * Ms;
+    static_assert(LL == 0 && G::B == 5 && P == 32, "thread t holds positions 32 t + q");
+    constexpr int RS = 33 * T / 32;
+    static_assert(RS * P <= G::LDS_FLOAT2, "transpose image fits the exchange buffer");
 #pragma unroll
-    for (int q = 0; q < P; ++q) {
-        const unsigned pos = (unsigned)pos_of<G::B, LL>(tid, q);  // position holds bin brev(pos)
-        stg2(y + (__brev(pos) >> (32 - G::m)), v[q]);
-    }
+    for (int q = 0; q < P; ++q) lds[RS * q + big_row<G>(tid)] = v[q];
+    __syncthreads();
+    const int rrow = big_row<G>(big_brev_tid<G>(tid));
+#pragma unroll
+    for (int q = 0; q < P; ++q) v[q] = lds[RS * q + rrow];
+#pragma unroll
+    for (int q = 0; q < P; ++q) stg2(y + tid + T * brev_c(q, 5), v[q]);  // bin t + T brev5(q)
 }
 
 template <int LOG2NS>
@@ -1931,16 +1960,28 @@ __global__ __launch_bounds__(Geo<LOG2NS>::T, 2) void big_c_kernel(const BigParam
     ctx.tid = threadIdx.x;
     fill_lds_bases<G, G::m>(ctx);
     const int tid = ctx.tid;
-    const uint32_t sub = blockIdx.x & 3u;
-    const int64_t hop_local = blockIdx.x >> 2;
+    uint32_t sub;
+    int64_t hop_local;
+    big_block(blockIdx.x, sub, hop_local);
+    if (hop_local >= p.hop_count) return;
     const uint32_t ch = blockIdx.y;
     const size_t hop_idx = (size_t)ch * p.hop_count + (size_t)hop_local;
     GV2 u = (GV2)p.ysub + (hop_idx * 4 + sub) * Ms;
     float2 v[P];
+    static_assert(LL == 0 && G::B == 5 && P == 32, "thread t holds positions 32 t + q");
+    constexpr int RS = 33 * T / 32;
+    // coalesced load of bins t + T brev5(q) = the registers of thread brev(t); hand them over
 #pragma unroll
-    for (int q = 0; q < P; ++q) {
-        const unsigned pos = (unsigned)pos_of<G::B, LL>(tid, q);
-        v[q] = ldg2(u + (__brev(pos) >> (32 - G::m)));
+    for (int q = 0; q < P; ++q) v[q] = ldg2(u + tid + T * brev_c(q, 5));
+    {
+        const int wrow = big_row<G>(big_brev_tid<G>(tid));
+#pragma unroll
+        for (int q = 0; q < P; ++q) lds[RS * q + wrow] = v[q];
+        __syncthreads();
+        const int rrow = big_row<G>(tid);
+#pragma unroll
+        for (int q = 0; q < P; ++q) v[q] = lds[RS * q + rrow];
+        __syncthreads();
     }
     Stamps st;
     st.init();
@@ -2063,7 +2104,7 @@ __global__ __launch_bounds__(256) void big_b_kernel(const BigParams p) {
 template <int LOG2NS>
 hipError_t launch_big_ac(int stage, const BigParams &p, hipStream_t s) {
     using G = Geo<LOG2NS>;
-    const dim3 grid((unsigned)(p.hop_count * 4), p.n_channels), block(G::T);
+    const dim3 grid((unsigned)((p.hop_count + 7) / 8 * 32), p.n_channels), block(G::T);
     const size_t lds = sizeof(float2) * G::LDS_FLOAT2;
     if (stage == 0) hipLaunchKernelGGL((big_a_kernel<LOG2NS>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((big_c_kernel<LOG2NS>), grid, block, lds, s, p);
