@@ -173,6 +173,17 @@ struct rc_engine {
     DevBuf d_in, d_out, d_spec, d_ybuf, d_ysub, d_tail, d_hop_in, d_hop_out, d_xtail;
     std::vector<float> h_spec, h_spec2, h_io;
     bool tail_zeroed = false;
+    // user-kernel path: two chunk-sized resource sets so that the forward transform + D2H of chunk
+    // i, the host apply() calls of chunk i - 1 and the H2D + resynthesis + overlap-add of chunk i - 2
+    // overlap (streams kf / kb beside the caller's stream; pinned host buffers)
+    struct KernelPipe {
+        DevBuf d_spec[2], d_ybuf[2], d_ysub[2];
+        float *h_in[2] = {nullptr, nullptr}, *h_out[2] = {nullptr, nullptr};
+        size_t h_cap = 0;
+        hipStream_t kf = nullptr, kb = nullptr;
+        hipEvent_t ev_fwd[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
+        hipEvent_t ev_in = nullptr, ev_done = nullptr;
+    } kp;
 };
 
 namespace {
@@ -257,6 +268,159 @@ rc::BigParams big_params(const rc_engine *e, const rc::HopParams &p) {
 
 int check_gpu_path(const rc_engine *e) {
     (void)e;
+    return RC_OK;
+}
+
+// User frequency kernel (src/fft.rs:76-108), hops [hop_first, hop_first + hop_count): forward transform
+// -> D2H -> apply() per hop on this host thread, in the reference's order (windows outer, channels
+// inner, hops of a window innermost: src/stretcher_processor.rs:63-70) -> H2D -> resynthesis ->
+// gather-form overlap-add with the tail carried in d_tail. apply() may be stateful, so no hop is
+// ever recomputed. Chunks of <= 32 MiB of spectrum run as a three-stage pipeline over two resource
+// sets: while the host works through chunk i - 1, stream kf produces chunk i and stream kb finishes
+// chunk i - 2.
+int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uint32_t n_channels,
+                    int64_t hop_first, int64_t hop_count, float *d_out, size_t out_stride,
+                    int64_t out_origin, hipStream_t s, uint32_t *launches) {
+    rc_engine::KernelPipe &kp = e->kp;
+    const uint32_t N = e->par.window_len, H = N / 2;
+    const bool big = e->log2n > 14;
+    const int64_t hpw = e->par.hops_per_window;
+    if (!kp.kf) {
+        RC_HIP(hipStreamCreateWithFlags(&kp.kf, hipStreamNonBlocking));
+        RC_HIP(hipStreamCreateWithFlags(&kp.kb, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            RC_HIP(hipEventCreateWithFlags(&kp.ev_fwd[i], hipEventDisableTiming));
+            RC_HIP(hipEventCreateWithFlags(&kp.ev_back[i], hipEventDisableTiming));
+        }
+        RC_HIP(hipEventCreateWithFlags(&kp.ev_in, hipEventDisableTiming));
+        RC_HIP(hipEventCreateWithFlags(&kp.ev_done, hipEventDisableTiming));
+    }
+    const size_t hop_bytes = (size_t)N * 2 * sizeof(float) * n_channels;  // one hop index, all channels
+    int64_t kc_max = (int64_t)(((size_t)32 << 20) / hop_bytes) / hpw * hpw;
+    kc_max = std::max<int64_t>(hpw, std::min<int64_t>(kc_max, (hop_count + hpw - 1) / hpw * hpw));
+    const size_t chunk_bytes = (size_t)kc_max * hop_bytes;
+    for (int i = 0; i < 2; ++i) {
+        if (int rc = kp.d_spec[i].reserve(chunk_bytes)) return rc;
+        if (int rc = kp.d_ybuf[i].reserve(chunk_bytes / 2)) return rc;
+        if (big)
+            if (int rc = kp.d_ysub[i].reserve(chunk_bytes / 2)) return rc;
+    }
+    if (kp.h_cap < chunk_bytes) {
+        for (int i = 0; i < 2; ++i) {
+            if (kp.h_in[i]) (void)hipHostFree(kp.h_in[i]);
+            if (kp.h_out[i]) (void)hipHostFree(kp.h_out[i]);
+            kp.h_in[i] = kp.h_out[i] = nullptr;
+        }
+        kp.h_cap = 0;
+        for (int i = 0; i < 2; ++i) {
+            RC_HIP(hipHostMalloc((void **)&kp.h_in[i], chunk_bytes, hipHostMallocDefault));
+            RC_HIP(hipHostMalloc((void **)&kp.h_out[i], chunk_bytes, hipHostMallocDefault));
+        }
+        kp.h_cap = chunk_bytes;
+    }
+    // kf and kb start after everything already queued on the caller's stream
+    RC_HIP(hipEventRecord(kp.ev_in, s));
+    RC_HIP(hipStreamWaitEvent(kp.kf, kp.ev_in, 0));
+    RC_HIP(hipStreamWaitEvent(kp.kb, kp.ev_in, 0));
+
+    auto params_of = [&](int set, int64_t k0, int64_t kc, rc::BigParams *b) {
+        rc::HopParams q = p;
+        q.spec = (float2 *)kp.d_spec[set].p;
+        q.ybuf = (float *)kp.d_ybuf[set].p;
+        q.ch_first = ch_first;
+        q.n_channels = n_channels;
+        q.hop_first = k0;
+        q.hop_count = kc;
+        if (big) {
+            *b = big_params(e, q);
+            b->ysub = (float2 *)kp.d_ysub[set].p;
+            b->ybuf = q.ybuf;
+            b->spec = q.spec;
+        } else {
+            plan_runs(e, n_channels, kc, &q.runs_per_channel, &q.run_len);
+        }
+        return q;
+    };
+    auto front = [&](int i, int64_t k0, int64_t kc) -> int {  // forward transform + D2H on kf
+        const int set = i & 1;
+        if (i >= 2) RC_HIP(hipStreamWaitEvent(kp.kf, kp.ev_back[set], 0));  // set free again
+        rc::BigParams b{};
+        const rc::HopParams q = params_of(set, k0, kc, &b);
+        if (big) {
+            RC_HIP(rc::launch_big(0, b, kp.kf));
+            RC_HIP(rc::launch_big(1, b, kp.kf, rc::MODE_FORWARD));
+            *launches += 2;
+        } else {
+            RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, q, kp.kf));
+            *launches += 1;
+        }
+        RC_HIP(hipMemcpyAsync(kp.h_in[set], kp.d_spec[set].p, (size_t)kc * hop_bytes,
+                              hipMemcpyDeviceToHost, kp.kf));
+        RC_HIP(hipEventRecord(kp.ev_fwd[set], kp.kf));
+        return RC_OK;
+    };
+    auto back = [&](int i, int64_t k0, int64_t kc) -> int {  // apply() here, then H2D .. OLA on kb
+        const int set = i & 1;
+        RC_HIP(hipEventSynchronize(kp.ev_fwd[set]));
+        for (int64_t w0 = 0; w0 < kc; w0 += hpw) {
+            for (uint32_t c = 0; c < n_channels; ++c) {
+                for (int64_t h = w0; h < std::min<int64_t>(w0 + hpw, kc); ++h) {
+                    const size_t off = ((size_t)c * kc + h) * N * 2;
+                    // src/fft.rs:86-99: apply(now_ms, bins) -> bins
+                    const int krc = e->cfg.kernel(now_ms(e), kp.h_in[set] + off, kp.h_out[set] + off, N,
+                                                  e->cfg.kernel_user);
+                    // non-zero == panic: keep the unmodified spectrum (src/fft.rs:100-106)
+                    if (krc != 0) memcpy(kp.h_out[set] + off, kp.h_in[set] + off, (size_t)N * 2 * sizeof(float));
+                }
+            }
+        }
+        RC_HIP(hipMemcpyAsync(kp.d_spec[set].p, kp.h_out[set], (size_t)kc * hop_bytes,
+                              hipMemcpyHostToDevice, kp.kb));
+        rc::BigParams b{};
+        const rc::HopParams q = params_of(set, k0, kc, &b);
+        if (big) {
+            RC_HIP(rc::launch_big(1, b, kp.kb, rc::MODE_RESYNTH));
+            RC_HIP(rc::launch_big(2, b, kp.kb));
+            *launches += 2;
+        } else {
+            RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, q, kp.kb));
+            *launches += 1;
+        }
+        rc::OlaParams o{};
+        o.ybuf = (const float *)kp.d_ybuf[set].p;
+        o.tail = (float *)e->d_tail.p + (size_t)ch_first * H;
+        o.out = d_out;
+        o.out_stride = out_stride;
+        o.out_origin = out_origin;
+        o.env = e->d_env;
+        o.amp = e->par.corrected_amp_factor;
+        o.pitch = e->cfg.pitch_multiple;
+        o.samples_needed = (uint32_t)e->par.samples_needed_per_window;
+        o.window_out_len = e->par.window_out_len;
+        o.n_channels = n_channels;
+        o.hop_first = k0;
+        o.hop_count = kc;
+        o.log2n = (uint32_t)e->log2n;
+        RC_HIP(rc::launch_ola(o, kp.kb, false));
+        *launches += 2;
+        RC_HIP(hipEventRecord(kp.ev_back[set], kp.kb));
+        return RC_OK;
+    };
+    int i = 0;
+    int64_t prev_k0 = 0, prev_kc = 0;
+    for (int64_t k0 = hop_first; k0 < hop_first + hop_count; k0 += kc_max, ++i) {
+        const int64_t kc = std::min<int64_t>(kc_max, hop_first + hop_count - k0);
+        if (int rc = front(i, k0, kc)) return rc;
+        if (i > 0)
+            if (int rc = back(i - 1, prev_k0, prev_kc)) return rc;
+        prev_k0 = k0;
+        prev_kc = kc;
+    }
+    if (i > 0)
+        if (int rc = back(i - 1, prev_k0, prev_kc)) return rc;
+    // the caller's stream continues after the last overlap-add
+    RC_HIP(hipEventRecord(kp.ev_done, kp.kb));
+    RC_HIP(hipStreamWaitEvent(s, kp.ev_done, 0));
     return RC_OK;
 }
 
@@ -463,6 +627,11 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
                               (size_t)n_channels * H * sizeof(float), s));
     else if (!e->cfg.kernel && (rc = run_chunk(hop_first - 1, 1, true)))
         return rc;
+    if (e->cfg.kernel) {
+        if ((rc = run_hops_kernel(e, p, ch_first, n_channels, hop_first, hop_count, d_out, out_stride,
+                                  out_origin, s, &launches)))
+            return rc;
+    } else
     for (int64_t k0 = hop_first; k0 < hop_first + hop_count; k0 += chunk_max) {
         const int64_t kc = std::min<int64_t>(chunk_max, hop_first + hop_count - k0);
         if ((rc = run_chunk(k0, kc, false))) return rc;
@@ -686,6 +855,19 @@ void rc_engine_destroy(rc_engine *e) {
     e->d_hop_in.release();
     e->d_hop_out.release();
     e->d_xtail.release();
+    for (int i = 0; i < 2; ++i) {
+        e->kp.d_spec[i].release();
+        e->kp.d_ybuf[i].release();
+        e->kp.d_ysub[i].release();
+        if (e->kp.h_in[i]) (void)hipHostFree(e->kp.h_in[i]);
+        if (e->kp.h_out[i]) (void)hipHostFree(e->kp.h_out[i]);
+        if (e->kp.ev_fwd[i]) (void)hipEventDestroy(e->kp.ev_fwd[i]);
+        if (e->kp.ev_back[i]) (void)hipEventDestroy(e->kp.ev_back[i]);
+    }
+    if (e->kp.ev_in) (void)hipEventDestroy(e->kp.ev_in);
+    if (e->kp.ev_done) (void)hipEventDestroy(e->kp.ev_done);
+    if (e->kp.kf) (void)hipStreamDestroy(e->kp.kf);
+    if (e->kp.kb) (void)hipStreamDestroy(e->kp.kb);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
