@@ -237,7 +237,6 @@ rc::HopParams base_params(const rc_engine *e) {
     p.step = e->par.sample_step_len;
     p.pitch = (uint32_t)std::max(1, e->cfg.pitch_multiple);
     p.seed_mixed = e->seed_mixed;
-    p.stagger_div = (uint32_t)std::max(1, e->n_cu);
     return p;
 }
 

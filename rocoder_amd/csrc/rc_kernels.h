@@ -39,7 +39,6 @@ struct HopParams {
     int64_t hop_count;
     uint32_t runs_per_channel;
     uint32_t run_len;
-    uint32_t stagger_div;  // workgroups b and b + stagger_div are expected to share a CU
     // spectrum modes (user-kernel path)
     float2 *spec;          // [n_channels][hop_count][N] natural-order spectrum
     float *ybuf;           // [n_channels][hop_count][N] windowed resynthesis output y_k

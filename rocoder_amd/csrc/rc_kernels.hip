@@ -67,12 +67,6 @@ constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }
 #ifndef RC_ABLATE
 #define RC_ABLATE 0
 #endif
-// Two workgroups share a CU and run identical code: left alone they execute in lockstep (both in
-// their LDS/global wait phases, then both contending for the SIMDs). RC_STAGGER delays every other
-// workgroup by that many s_sleep(127) (8128 cycles each) once, so one computes while the other waits.
-#ifndef RC_STAGGER
-#define RC_STAGGER 0
-#endif
 #ifndef RC_LOADCH
 #define RC_LOADCH 32
 #endif
@@ -159,9 +153,6 @@ __device__ __forceinline__ void opaque(int &x) { asm volatile("" : "+v"(x)); }
 // per phase id, written to the debug buffer passed in HopParams::spec.
 #ifndef RC_STAMP
 #define RC_STAMP 0
-#endif
-#ifndef RC_XPREFETCH
-#define RC_XPREFETCH 1
 #endif
 #ifndef RC_SWP
 #define RC_SWP 2
@@ -686,20 +677,6 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
     GV2 wtab = (GV2)p.wtab;
     GV2 rtab = (GV2)p.rtab;
 
-    if (RC_STAGGER > 0) {
-        // wave slot of this workgroup's first wave on its SIMD (HW_REG_HW_ID[3:0]): the two
-        // workgroups sharing a CU sit in different slots
-        if (threadIdx.x == 0) {
-            const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-            reinterpret_cast<unsigned *>(lds)[0] = slot;
-        }
-        __syncthreads();
-        const unsigned slot = reinterpret_cast<volatile unsigned *>(lds)[0];
-        __syncthreads();
-        if (slot & 1) {
-            for (int i = 0; i < RC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
     float2 v[P];
     Stamps st;
     st.init();
@@ -861,25 +838,9 @@ __device__ __forceinline__ GF hop_src(const HopParams &p, GF xc, GF xt, int64_t 
 #ifndef RC_V2
 #define RC_V2 1
 #endif
-#ifndef RC_PRIO
-#define RC_PRIO 0
-#endif
-#ifndef RC_LDS_PAD
-#define RC_LDS_PAD 0  // diagnostic: extra dynamic LDS to force one workgroup per CU
-#endif
 constexpr int f1_idx(int n) { return n + (n >> 5); }
-// RC_HALFEXP: TIMING-ONLY experiment (results are wrong): exchange addresses wrap into a half-size
-// buffer so that three workgroups fit one CU; RC_HALFEXP - 1 extra barriers per exchange
-#ifndef RC_HALFEXP
-#define RC_HALFEXP 0
-#endif
-constexpr int HOP2_XM = RC_HALFEXP ? 4095 : 8191;
-constexpr int HOP2_XBUF = RC_HALFEXP ? (4096 + 128 + 16) : (8192 + 256 + 32);
+constexpr int HOP2_XBUF = 8192 + 256 + 32;
 constexpr int HOP2_LDS_FLOAT2 = HOP2_XBUF + 8 + 32 + 256 + 256 + 16 + 24 + 1024;  // 79 232 B
-__device__ __forceinline__ void xbar() {
-#pragma unroll
-    for (int i = 1; i < RC_HALFEXP; ++i) __syncthreads();
-}
 // LDS index map of the exchange buffer: a weight per position bit, so the map is additive over
 // disjoint bit fields (per-thread base VGPR + immediate offset per register). The weights were searched
 // (banking model of MI355X_MICROARCH.md: ds_write_b64 = 16-lane groups on 32 banks, ds_read_b64 =
@@ -932,20 +893,7 @@ __device__ __forceinline__ void vdit_rot(v2f a, v2f b, v2f w, v2f w2r, v2f &r, v
 // wfine = W_{2^(S_HI+1)}^l, the base twiddle of the last stage; the base of stage s - 1 is the
 // square of the base of stage s (no table loads inside the hop loop: a global load waited on in
 // place costs its full latency, and vmcnt retires in order behind the output stores).
-// Exchange read of one complex: ds_read_b64 moves 256 B/clk/CU, but the compiler's DS merge pass
-// would pair neighbours into ds_read2_b64 (128 B/clk/CU: MI355X_MICROARCH.md LDS table); a volatile
-// access is left alone.
-#ifndef RC_XLD_VOLATILE
-#define RC_XLD_VOLATILE 0  // measured: no gain (LDS reads are not the limiter), kept for A/B
-#endif
-__device__ __forceinline__ v2f xld(const float2 *lds, int idx) {
-#if RC_XLD_VOLATILE
-    typedef const volatile v2f __attribute__((address_space(3))) *LV2;
-    return *(LV2)(lds + idx);
-#else
-    return to_v(lds[idx]);
-#endif
-}
+__device__ __forceinline__ v2f xld(const float2 *lds, int idx) { return to_v(lds[idx]); }
 // Runtime-twiddle butterflies with the (-w.y, w.y) / (w.x, -w.x) operand expressed as VOP3P source
 // modifiers (op_sel + neg_lo / neg_hi): hipcc does not fold a per-lane negation into the modifiers, so
 // the plain-C++ form needs one v_pk_mul per twiddle and form (124 per hop) to build those operands.
@@ -1155,7 +1103,7 @@ __device__ constexpr HannK HANN_W14 = make_hann_k(0.5, 16384, 32);
 __device__ constexpr HannK HANN_E14 = make_hann_k(HANN_ENV_AMP, 8192, 16);
 
 template <bool PITCH1, bool HANN>
-__global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const HopParams p) {
+__global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
     constexpr int LOG2N = 14, m = 13, M = 1 << m, H = M, T = 256, P = 32, PH = 16;
     constexpr int RES = 512;                      // residues of the last forward pass
     constexpr int SCR = HOP2_XBUF + 8;            // 32-element scratch for thread 0's pairs
@@ -1185,12 +1133,12 @@ __global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const Hop
     // residues of this thread and per-thread LDS bases (thread part of every access pattern)
     const int r = tid, rb = tid ? RES - tid : RES / 2;
     const int l4 = tid & 15, uu = tid >> 4;
-    const int pos4 = ((uu << 9) | l4) & HOP2_XM;                                  // LOR = 4 layout, q = 0
-    const int bE1s = f3_idx(((int)(__brev((unsigned)tid) >> 24) << 5) & HOP2_XM);  // brev8(t) << 5
+    const int pos4 = (uu << 9) | l4;                                  // LOR = 4 layout, q = 0
+    const int bE1s = f3_idx(((int)(__brev((unsigned)tid) >> 24) << 5));  // brev8(t) << 5
     const int b4f3 = f3_idx(pos4);
     const int bAr = f3_idx(r), bBr = f3_idx(rb);
-    const int bE3a = f3_idx(((int)(__brev((unsigned)r) >> 23) << 4) & HOP2_XM);    // brev9(r) << 4
-    const int bE3b = f3_idx(((int)(__brev((unsigned)rb) >> 23) << 4) & HOP2_XM);
+    const int bE3a = f3_idx(((int)(__brev((unsigned)r) >> 23) << 4));    // brev9(r) << 4
+    const int bE3b = f3_idx(((int)(__brev((unsigned)rb) >> 23) << 4));
     const int bE4l = f3_idx(tid);
 
     Stamps st;
@@ -1198,11 +1146,6 @@ __global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const Hop
     v2f tail[PH];
 #pragma unroll
     for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
-#if RC_PRIO
-    // the two workgroups of a CU run the same code; a static priority split keeps them from
-    // marching in lockstep (one computes while the other waits on LDS / memory)
-    if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(RC_PRIO);
-#endif
 
     {
         lds[T_A + tid] = ldg2(wtab + tid);
@@ -1220,24 +1163,12 @@ __global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const Hop
         }
         __syncthreads();
     }
-#if RC_STAGGER
-    {   // tuning builds: delay the workgroup in the odd wave slot once, so the two workgroups of a CU
-        // do not reach their LDS exchanges together
-        if (tid == 0) reinterpret_cast<unsigned *>(lds + SCR)[0] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-        __syncthreads();
-        const unsigned slot = reinterpret_cast<volatile unsigned *>(lds + SCR)[0];
-        __syncthreads();
-        if (slot & 1)
-            for (int i = 0; i < RC_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     // The hop loop is software-pipelined (RC_SWP): the LDS stores of an exchange drain for ~800
     // cycles during which the wave would only wait at the barrier, so the next hop's window multiply
     // and first pass F1 (registers only) run between the E3 store and its barrier; the next hop's
     // samples are requested before I1. vn carries F1's output into the next iteration.
-    //   RC_SWP = 0: plain order (optionally with the raw-input prefetch RC_XPREFETCH, HANN only)
+    //   RC_SWP = 0: plain order
     constexpr bool SWP = RC_SWP != 0 && HANN;  // (the table-window variant has no registers to spare)
-    constexpr bool XPF = !SWP && HANN && RC_XPREFETCH != 0;
     float xr0[P], xr1[P];
     auto issue_x = [&](int64_t kk) {
         GF src = hop_src(p, xc, xt, kk);
@@ -1362,13 +1293,13 @@ __global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const Hop
     constexpr bool SWP2 = SWP && RC_SWP >= 2;
     v2f vo[P];  // SWP2: I3 output of the previous hop, its epilogue still to run
     v2f vn[P];
-    if constexpr (XPF || SWP) issue_x(k_first);
+    if constexpr (SWP) issue_x(k_first);
     if constexpr (SWP) win_f1(vn);
     for (int64_t k = k_first; k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         v2f v[P];
         if constexpr (!SWP) {
-            if constexpr (!XPF) issue_x(k);
+            issue_x(k);
             win_f1(vn);
         }
         // ---- forward: F1 (done), E1, F2 (bits 5..8), E2, F3 (bits 9..12)
@@ -1386,7 +1317,6 @@ __global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const Hop
         st.mark(3);
 #pragma unroll
         for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 256))) v[q] = xld(lds, b4f3 + f3_idx(q << 4));
-        xbar();
         dit_stages<32, m, 5, 8, 4, false, true>(v, to_v(lds[T_B + l4]));
         st.mark(4);
         // E2 store is IN PLACE (same layout, same index map as the E1 load): each thread overwrites
@@ -1400,15 +1330,14 @@ __global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const Hop
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             if (!(RC_ABLATE & (4 | 256))) {
-                va[q] = xld(lds, bAr + f3_idx((RES * q) & HOP2_XM));
-                vb[q] = xld(lds, bBr + f3_idx((RES * q) & HOP2_XM));
+                va[q] = xld(lds, bAr + f3_idx((RES * q)));
+                vb[q] = xld(lds, bBr + f3_idx((RES * q)));
             } else {
                 va[q] = v[q];
                 vb[q] = v[q + 16];
             }
         }
         st.mark(7);
-        xbar();
         if (!(RC_ABLATE & 32)) __syncthreads();
         st.mark(8);
         {
@@ -1504,7 +1433,6 @@ __global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const Hop
         st.mark(14);
 #pragma unroll
         for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 256))) v[q] = xld(lds, b4f3 + f3_idx(q << 4));
-        xbar();
         dit_stages<32, m, 4, 8, 4, true, true>(v, to_v(lds[T_B + l4]));
         st.mark(15);
 #pragma unroll
@@ -1513,22 +1441,11 @@ __global__ __launch_bounds__(256, RC_HALFEXP ? 3 : 2) void hop2_kernel(const Hop
         if (!(RC_ABLATE & 32)) __syncthreads();
         st.mark(17);
 #pragma unroll
-        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 256))) v[q] = xld(lds, bE4l + f3_idx((q << 8) & HOP2_XM));
+        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 256))) v[q] = xld(lds, bE4l + f3_idx((q << 8)));
         st.mark(18);
-        xbar();
         if (!(RC_ABLATE & 32)) __syncthreads();
         st.mark(19);
-        if constexpr (XPF && RC_XPREFETCH == 2) {  // (the last hop re-reads itself)
-            __builtin_amdgcn_sched_barrier(0);
-            issue_x(k + 1 < k_end ? k + 1 : k);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         dit_stages<32, m, 9, 12, 8, true, true>(v, to_v(lds[T_A + tid]));
-        if constexpr (XPF && RC_XPREFETCH == 1) {  // (the last hop re-reads itself)
-            __builtin_amdgcn_sched_barrier(0);
-            issue_x(k + 1 < k_end ? k + 1 : k);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         st.mark(20);
 
         if constexpr (SWP2) {
@@ -1853,7 +1770,7 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
     switch (mode) {
         case MODE_FUSED:
             if (RC_V2 && LOG2N == 14) {
-                const size_t lds2 = sizeof(float2) * (size_t)HOP2_LDS_FLOAT2 + RC_LDS_PAD;
+                const size_t lds2 = sizeof(float2) * (size_t)HOP2_LDS_FLOAT2;
                 const bool hann = p.hann_rot != nullptr;
                 if (RC_V3 && hann) {
                     const size_t lds3 = sizeof(float2) * (size_t)HOP3_LDS_FLOAT2;
