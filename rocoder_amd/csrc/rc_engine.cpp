@@ -171,6 +171,10 @@ struct rc_engine {
     std::vector<Channel> ch;
     // scratch
     DevBuf d_in, d_out, d_spec, d_ybuf, d_ysub, d_tail, d_hop_in, d_hop_out, d_xtail;
+    // seam hand-over between the runs of hop3_kernel (HopParams::seam_*): stash [runs][H], one flag
+    // per run (compared with seam_epoch, so it is zeroed only when it is (re)allocated), run counter
+    DevBuf d_seam_head, d_seam_flag, d_run_counter;
+    uint32_t seam_epoch = 0;
     std::vector<float> h_spec, h_spec2, h_io;
     bool tail_zeroed = false;
     // user-kernel path: two chunk-sized resource sets so that the forward transform + D2H of chunk
@@ -485,6 +489,30 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         RC_HIP(hipMemsetAsync(e->d_spec.p, 0, n_dbg * sizeof(unsigned), s));
         p.spec = (float2 *)e->d_spec.p;
 #endif
+#ifndef RC_SEAM
+#define RC_SEAM 1
+#endif
+        if (RC_SEAM && rc::hop_workgroups_per_cu(e->log2n, e->d_hann_rot != nullptr) && p.runs_per_channel > 1) {
+            const size_t runs_total = (size_t)p.runs_per_channel * n_channels;
+            int rcs = e->d_seam_head.reserve(runs_total * H * sizeof(float));
+            if (rcs) return rcs;
+            const size_t flag_cap = e->d_seam_flag.cap;
+            if ((rcs = e->d_seam_flag.reserve(runs_total * sizeof(uint32_t)))) return rcs;
+            if (e->d_seam_flag.cap != flag_cap) {  // fresh allocation: no flag equals any epoch yet
+                RC_HIP(hipMemsetAsync(e->d_seam_flag.p, 0, e->d_seam_flag.cap, s));
+                e->seam_epoch = 0;
+            }
+            if ((rcs = e->d_run_counter.reserve(sizeof(uint32_t)))) return rcs;
+            RC_HIP(hipMemsetAsync(e->d_run_counter.p, 0, sizeof(uint32_t), s));
+            if (++e->seam_epoch == 0) {  // wrapped: start over with clean flags
+                RC_HIP(hipMemsetAsync(e->d_seam_flag.p, 0, e->d_seam_flag.cap, s));
+                e->seam_epoch = 1;
+            }
+            p.seam_head = (float *)e->d_seam_head.p;
+            p.seam_flag = (uint32_t *)e->d_seam_flag.p;
+            p.run_counter = (uint32_t *)e->d_run_counter.p;
+            p.seam_epoch = e->seam_epoch;
+        }
         if (timed) RC_HIP(hipEventRecord(e->ev0, s));
         RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FUSED, p, s));
 #ifdef RC_STAMP_DUMP
@@ -854,6 +882,9 @@ void rc_engine_destroy(rc_engine *e) {
     e->d_hop_in.release();
     e->d_hop_out.release();
     e->d_xtail.release();
+    e->d_seam_head.release();
+    e->d_seam_flag.release();
+    e->d_run_counter.release();
     for (int i = 0; i < 2; ++i) {
         e->kp.d_spec[i].release();
         e->kp.d_ybuf[i].release();

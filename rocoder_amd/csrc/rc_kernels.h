@@ -39,6 +39,15 @@ struct HopParams {
     int64_t hop_count;
     uint32_t runs_per_channel;
     uint32_t run_len;
+    // seam hand-over of hop3_kernel (null: every run recomputes the hop before it instead). The first
+    // hop of run g > 0 of a channel stashes its windowed head [H] at seam_head + g * H and publishes
+    // seam_flag[g] = seam_epoch; run g - 1 adds its last tail to it. Runs are numbered in the order
+    // their workgroups start (run_counter, zeroed per launch), so a run only ever waits for a
+    // workgroup that started after it and is already resident or next in line.
+    float *seam_head;
+    uint32_t *seam_flag;
+    uint32_t *run_counter;
+    uint32_t seam_epoch;
     // spectrum modes (user-kernel path)
     float2 *spec;          // [n_channels][hop_count][N] natural-order spectrum
     float *ybuf;           // [n_channels][hop_count][N] windowed resynthesis output y_k

@@ -1496,12 +1496,24 @@ __global__ __launch_bounds__(256, 3) void hop3_kernel(const HopParams p) {
     static_assert(T_H + 1024 == HOP3_LDS_FLOAT2, "LDS layout");
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
-    const uint32_t run = blockIdx.x % p.runs_per_channel;
-    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    // global run index: the order in which workgroups START when the seam hand-over is on
+    uint32_t gr = blockIdx.x;
+    const bool seam = p.seam_head != nullptr;
+    if (seam) {
+        unsigned *slot = reinterpret_cast<unsigned *>(lds + SCR);
+        if (tid == 0) *slot = atomicAdd(p.run_counter, 1u);
+        __syncthreads();
+        gr = *reinterpret_cast<volatile unsigned *>(slot);
+        __syncthreads();
+    }
+    const uint32_t run = gr % p.runs_per_channel;
+    const uint32_t ch = gr / p.runs_per_channel;
     const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
     int64_t k_end = k_begin + p.run_len;
     if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
     if (k_begin >= k_end) return;
+    const bool stash_first = seam && run > 0;                          // my first head goes to the stash
+    const bool has_next = seam && run + 1 < p.runs_per_channel;        // I finish my successor's first head
     GF xc = (GF)p.x + (size_t)ch * p.in_stride;
     GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
     GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
@@ -1537,7 +1549,43 @@ __global__ __launch_bounds__(256, 3) void hop3_kernel(const HopParams p) {
         __syncthreads();
     }
     const v2f half2 = {0.5f, 0.5f};
-    for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
+    // O[kk H + i] = (head[i] + tail[i]) * env[i] * amp for this thread's 32 head samples, decimated by
+    // the pitch multiple (src/stretcher.rs:96-112)
+    auto store_head = [&](int64_t kk, const auto &head) {
+        const v2f cbE = to_v(lds[T_H + 2 * T + 2 * tid]), sbE = to_v(lds[T_H + 2 * T + 2 * tid + 1]);
+        const int64_t g0 = kk * (int64_t)H;
+        if constexpr (PITCH1) {
+            GFW dst = outc + (g0 - p.out_origin);
+            const v2f amp2 = {p.amp, p.amp};
+#pragma unroll
+            for (int q = 0; q < PH; ++q) {
+                const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
+                               __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, half2));
+                // stretcher.rs:97-100 operation order, both samples of the pair per instruction
+                const v2f o = (head[q] + tail[q]) * er * amp2;
+                *(GV2W)(dst + 2 * T * q + lane2) = o;
+            }
+        } else {
+            const int64_t kq = g0 / pitch;
+            const uint32_t kr = (uint32_t)(g0 % pitch);
+            GFW dst = outc + (kq - p.out_origin);
+            int t2 = tid;
+            opaque(t2);
+#pragma unroll
+            for (int q = 0; q < PH; ++q) {
+                const uint32_t i0 = 2u * (uint32_t)(t2 + T * q);
+                const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
+                               __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, half2));
+                const v2f o = (head[q] + tail[q]) * er * v2f{p.amp, p.amp};
+                const uint32_t a0 = kr + i0, a1 = a0 + 1;
+                const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
+                if (d0 * pitch == a0) dst[d0] = o.x;
+                if (d1 * pitch == a1) dst[d1] = o.y;
+            }
+        }
+    };
+    // hop k_begin - 1 is recomputed for its tail only where no other run hands the seam over
+    for (int64_t k = ((k_begin > 0 && !stash_first) ? k_begin - 1 : k_begin); k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         v2f v[P];
         {   // register brev5(q) := z[q * T + t] * window ; F1 = stages 0..4
@@ -1679,45 +1727,53 @@ __global__ __launch_bounds__(256, 3) void hop3_kernel(const HopParams p) {
 
         // ---- epilogue: synthesis window, overlap-add with the carried tail, store
         const v2f cbW = to_v(lds[T_H + 2 * tid]), sbW = to_v(lds[T_H + 2 * tid + 1]);
-        const v2f cbE = to_v(lds[T_H + 2 * T + 2 * tid]), sbE = to_v(lds[T_H + 2 * T + 2 * tid + 1]);
 #pragma unroll
         for (int q = 0; q < P; ++q)
             y[q] *= __builtin_elementwise_fma(v2f{HANN_W14.s[q], HANN_W14.s[q]}, sbW,
                     __builtin_elementwise_fma(v2f{HANN_W14.c[q], HANN_W14.c[q]}, cbW, half2));
         if (k >= k_begin) {
-            const int64_t g0 = k * (int64_t)H;
-            if constexpr (PITCH1) {
-                GFW dst = outc + (g0 - p.out_origin);
-                const v2f amp2 = {p.amp, p.amp};
-#pragma unroll
-                for (int q = 0; q < PH; ++q) {
-                    const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
-                                   __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, half2));
-                    // stretcher.rs:97-100 operation order, both samples of the pair per instruction
-                    const v2f o = (y[q] + tail[q]) * er * amp2;
-                    *(GV2W)(dst + 2 * T * q + lane2) = o;
-                }
-            } else {
-                const int64_t kq = g0 / pitch;
-                const uint32_t kr = (uint32_t)(g0 % pitch);
-                GFW dst = outc + (kq - p.out_origin);
+            if (stash_first && k == k_begin) {
+                // the run before this one holds the tail that belongs to this head: stash the windowed
+                // head for it and publish (release at agent scope: the reader may sit on another XCD)
+                // agent-scope (write-through) stores and loads for the stash and its flag instead of
+                // release / acquire fences: a fence writes back or invalidates the whole XCD L2, and
+                // 6 000 of them per launch cost 9 %
                 int t2 = tid;
-                opaque(t2);
+                opaque(t2);  // keep the 16 store addresses out of the hop loop's live registers
+                unsigned long long *hs = (unsigned long long *)(p.seam_head + (size_t)gr * H) + t2;
 #pragma unroll
-                for (int q = 0; q < PH; ++q) {
-                    const uint32_t i0 = 2u * (uint32_t)(t2 + T * q);
-                    const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
-                                   __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, half2));
-                    const v2f o = (y[q] + tail[q]) * er * v2f{p.amp, p.amp};
-                    const uint32_t a0 = kr + i0, a1 = a0 + 1;
-                    const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
-                    if (d0 * pitch == a0) dst[d0] = o.x;
-                    if (d1 * pitch == a1) dst[d1] = o.y;
-                }
+                for (int q = 0; q < PH; ++q)
+                    __hip_atomic_store(hs + T * q, __builtin_bit_cast(unsigned long long, y[q]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have landed
+                __syncthreads();
+                if (tid == 0)
+                    __hip_atomic_store(p.seam_flag + gr, p.seam_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                store_head(k, y);
             }
         }
 #pragma unroll
         for (int q = 0; q < PH; ++q) tail[q] = y[q + PH];
+    }
+    if (has_next) {
+        // hop k_end is the first hop of run gr + 1: its workgroup started after this one and stashed
+        // the head one hop after its start. Bounded wait (never reached unless the launch is broken).
+        if (tid == 0) {
+            for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+                if (__hip_atomic_load(p.seam_flag + gr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                    p.seam_epoch)
+                    break;
+                __builtin_amdgcn_s_sleep(32);
+            }
+        }
+        __syncthreads();
+        const unsigned long long *hs = (const unsigned long long *)(p.seam_head + (size_t)(gr + 1) * H) + tid;
+        v2f head[PH];
+#pragma unroll
+        for (int q = 0; q < PH; ++q)
+            head[q] = __builtin_bit_cast(v2f, __hip_atomic_load(hs + T * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        store_head(k_end, head);
     }
 }
 
