@@ -414,6 +414,47 @@ def test_window_ranges_concatenate_to_full_output():
             assert torch.equal(out, full), f"world={world}"  # bit-exact: same hops, same kernel
 
 
+@pytest.mark.parametrize("p", [1, 3])
+def test_16384_runs_seams_and_ranges_bit_exact(p):
+    """hop3_kernel (window 16384, default hanning): one launch is cut into hundreds of runs whose seams
+    are handed over between workgroups (HopParams::seam_*), a range that does not start at hop 0
+    recomputes the hop before it instead, and both must give the same bits: every shard plan
+    concatenates to the full output, and repeated launches (flag epochs) repeat it exactly."""
+    import torch
+
+    ra = _engine_mod()
+    L = 2_500_000
+    x = np.stack([onp.synth_input(c, L) for c in range(2)])
+    xt = torch.from_numpy(x).cuda()
+    with ra.Engine(window_len=16384, factor=8.0, pitch_multiple=p, channels=2, seed=11) as e:
+        full = e.stretch_tensor(xt).clone()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            again = e.stretch_tensor(xt)
+            torch.cuda.synchronize()
+            assert torch.equal(again, full)
+        wout = e.params.window_out_len
+        nwin = full.shape[1] // wout
+        from rocoder_amd.distributed import engine_compute, shard_plan
+
+        comp = engine_compute(e, xt)
+        for world in (2, 3, 7):
+            plan = shard_plan(2, nwin, world)
+            out = torch.zeros_like(full)
+            for s in plan:
+                blk = comp(s)
+                out[s.ch_first:s.ch_first + s.ch_count,
+                    s.win_first * wout:(s.win_first + s.win_count) * wout] = blk
+            torch.cuda.synchronize()
+            assert torch.equal(out, full), f"world={world}"
+    # and the whole thing against the oracle on a prefix (the oracle needs seconds per million samples)
+    Lp = 300_000
+    ref = oc.stretch_offline(x[:, :Lp], 16384, 8.0, 1.0, p, seed=11)
+    with ra.Engine(window_len=16384, factor=8.0, pitch_multiple=p, channels=2, seed=11) as e:
+        got = e.stretch_tensor(torch.from_numpy(np.ascontiguousarray(x[:, :Lp])).cuda()).cpu().numpy()
+    assert_parity(got, ref, f"prefix p={p}")
+
+
 def test_large_window_ranges_concatenate_to_full_output():
     import torch
 
