@@ -1474,6 +1474,9 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
 #ifndef RC_V3
 #define RC_V3 1
 #endif
+#ifndef RC_NTSTORE
+#define RC_NTSTORE 1
+#endif
 constexpr int G12_W[12] = {1, 2, 4, 8, 16, 32, 66, 130, 263, 526, 1052, 2104};  // searched like F3_W
 constexpr int g_idx(int n) {
     int r = 0;
@@ -1563,7 +1566,11 @@ __global__ __launch_bounds__(256, 3) void hop3_kernel(const HopParams p) {
                                __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, half2));
                 // stretcher.rs:97-100 operation order, both samples of the pair per instruction
                 const v2f o = (head[q] + tail[q]) * er * amp2;
+#if RC_NTSTORE
+                __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));  // written once, never re-read here
+#else
                 *(GV2W)(dst + 2 * T * q + lane2) = o;
+#endif
             }
         } else {
             const int64_t kq = g0 / pitch;
