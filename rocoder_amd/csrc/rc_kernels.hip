@@ -203,6 +203,16 @@ template <class G, int LOR, int S_LO, int S_HI, bool INV>
 __device__ __forceinline__ void run_pass(float2 (&v)[G::P], int tid,
                                          GV2 wtab) {
     const int l = tid & ((1 << LOR) - 1);
+    // the base twiddles of all stages of the pass are requested together and waited on once (each
+    // used to be waited on in place, one memory latency per stage); the opaque copies keep them from
+    // being hoisted out of the hop loop into live registers
+    float2 bases[S_HI - S_LO + 1];
+    if (LOR > 0) {
+#pragma unroll
+        for (int si = 0; si <= S_HI - S_LO; ++si) bases[si] = ldg2(wtab + (l << (G::m - 1 - (S_LO + si))));
+#pragma unroll
+        for (int si = 0; si <= S_HI - S_LO; ++si) opaque(bases[si]);
+    }
 #pragma unroll
     for (int si = 0; si <= S_HI - S_LO; ++si) {
         const int s = INV ? (S_LO + si) : (S_HI - si);
@@ -210,10 +220,7 @@ __device__ __forceinline__ void run_pass(float2 (&v)[G::P], int tid,
         const int half = 1 << r;
         if (RC_ABLATE & 8) continue;
         float2 base = make_float2(1.f, 0.f);
-        if (LOR > 0) {
-            base = ldg2(wtab + (l << (G::m - 1 - s)));
-            opaque(base);
-        }
+        if (LOR > 0) base = bases[s - S_LO];
 #pragma unroll
         for (int q0 = 0; q0 < G::P; ++q0) {
             if (q0 & half) continue;
