@@ -493,25 +493,26 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
 #define RC_SEAM 1
 #endif
         if (RC_SEAM && rc::hop_workgroups_per_cu(e->log2n, e->d_hann_rot != nullptr) && p.runs_per_channel > 1) {
+            // (no memory for the stash is not an error: the kernel then recomputes one hop per run)
             const size_t runs_total = (size_t)p.runs_per_channel * n_channels;
-            int rcs = e->d_seam_head.reserve(runs_total * H * sizeof(float));
-            if (rcs) return rcs;
             const size_t flag_cap = e->d_seam_flag.cap;
-            if ((rcs = e->d_seam_flag.reserve(runs_total * sizeof(uint32_t)))) return rcs;
-            if (e->d_seam_flag.cap != flag_cap) {  // fresh allocation: no flag equals any epoch yet
-                RC_HIP(hipMemsetAsync(e->d_seam_flag.p, 0, e->d_seam_flag.cap, s));
-                e->seam_epoch = 0;
+            if (e->d_seam_head.reserve(runs_total * H * sizeof(float)) == RC_OK &&
+                e->d_seam_flag.reserve(runs_total * sizeof(uint32_t)) == RC_OK &&
+                e->d_run_counter.reserve(sizeof(uint32_t)) == RC_OK) {
+                if (e->d_seam_flag.cap != flag_cap) {  // fresh allocation: no flag equals any epoch yet
+                    RC_HIP(hipMemsetAsync(e->d_seam_flag.p, 0, e->d_seam_flag.cap, s));
+                    e->seam_epoch = 0;
+                }
+                RC_HIP(hipMemsetAsync(e->d_run_counter.p, 0, sizeof(uint32_t), s));
+                if (++e->seam_epoch == 0) {  // wrapped: start over with clean flags
+                    RC_HIP(hipMemsetAsync(e->d_seam_flag.p, 0, e->d_seam_flag.cap, s));
+                    e->seam_epoch = 1;
+                }
+                p.seam_head = (float *)e->d_seam_head.p;
+                p.seam_flag = (uint32_t *)e->d_seam_flag.p;
+                p.run_counter = (uint32_t *)e->d_run_counter.p;
+                p.seam_epoch = e->seam_epoch;
             }
-            if ((rcs = e->d_run_counter.reserve(sizeof(uint32_t)))) return rcs;
-            RC_HIP(hipMemsetAsync(e->d_run_counter.p, 0, sizeof(uint32_t), s));
-            if (++e->seam_epoch == 0) {  // wrapped: start over with clean flags
-                RC_HIP(hipMemsetAsync(e->d_seam_flag.p, 0, e->d_seam_flag.cap, s));
-                e->seam_epoch = 1;
-            }
-            p.seam_head = (float *)e->d_seam_head.p;
-            p.seam_flag = (uint32_t *)e->d_seam_flag.p;
-            p.run_counter = (uint32_t *)e->d_run_counter.p;
-            p.seam_epoch = e->seam_epoch;
         }
         if (timed) RC_HIP(hipEventRecord(e->ev0, s));
         RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FUSED, p, s));
