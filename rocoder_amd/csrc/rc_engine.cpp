@@ -703,6 +703,20 @@ int single_hop_resynth(rc_engine *e, const rc::HopParams &p) {
     return RC_OK;
 }
 
+// No C++ exception may cross the C-ABI (a Rust or C host cannot unwind through it): every entry
+// point that allocates is a function-try-block that maps what it catches to a status code.
+int rc_catch() noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        return fail(RC_ENOMEM, "host allocation failed");
+    } catch (const std::exception &ex) {
+        return fail(RC_EHIP, "internal error: %s", ex.what());
+    } catch (...) {
+        return fail(RC_EHIP, "internal error");
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -752,7 +766,7 @@ float rc_phase_theta(uint64_t key, uint32_t bin, uint32_t n_bins) {
     return u * 3.14159265358979323846f;
 }
 
-int rc_engine_create(const rc_config *cfg, rc_engine **out) {
+int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
     if (!out) return fail(RC_EINVAL, "null out");
     *out = nullptr;
     rc_params par;
@@ -862,6 +876,8 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) {
 #undef RC_HIP_C
     *out = e;
     return RC_OK;
+} catch (...) {
+    return rc_catch();
 }
 
 void rc_engine_destroy(rc_engine *e) {
@@ -918,13 +934,15 @@ size_t rc_engine_channel_bound(const rc_engine *e) {
     return (size_t)ceilf(v);
 }
 
-int rc_engine_push_input(rc_engine *e, uint32_t channel, const float *samples, size_t n) {
+int rc_engine_push_input(rc_engine *e, uint32_t channel, const float *samples, size_t n) try {
     if (!e || channel >= e->ch.size() || (!samples && n)) return fail(RC_EINVAL, "bad argument");
     Channel &c = e->ch[channel];
     if (c.closed) return fail(RC_EINVAL, "channel %u is closed", channel);
     c.fifo.insert(c.fifo.end(), samples, samples + n);
     c.total_in += n;
     return RC_OK;
+} catch (...) {
+    return rc_catch();
 }
 
 int rc_engine_close_input(rc_engine *e, uint32_t channel) {
@@ -939,7 +957,7 @@ int rc_engine_is_done(const rc_engine *e, uint32_t channel) {
     return (c.done_window >= 0 && (int64_t)c.windows_out > c.done_window) ? 1 : 0;
 }
 
-int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out_cap, size_t *n_out) {
+int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out_cap, size_t *n_out) try {
     if (!e || channel >= e->ch.size() || !out) return fail(RC_EINVAL, "bad argument");
     int rc = check_gpu_path(e);
     if (rc) return rc;
@@ -1012,12 +1030,14 @@ int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out
     c.ready.pop_front();
     c.windows_out++;
     return RC_OK;
+} catch (...) {
+    return rc_catch();
 }
 
 int rc_engine_stretch_device_range(rc_engine *e, const float *d_in, size_t in_stride, size_t in_len,
                                    uint32_t ch_first, uint32_t ch_count, uint64_t win_first,
                                    uint64_t win_count, float *d_out, size_t out_stride,
-                                   size_t out_cap, void *hip_stream) {
+                                   size_t out_cap, void *hip_stream) try {
     if (!e || !d_out || (!d_in && in_len)) return fail(RC_EINVAL, "null argument");
     int rc = check_gpu_path(e);
     if (rc) return rc;
@@ -1034,21 +1054,25 @@ int rc_engine_stretch_device_range(rc_engine *e, const float *d_in, size_t in_st
     return run_hops(e, d_in + (size_t)ch_first * in_stride, in_stride, 0, (int64_t)in_len, ch_first,
                     ch_count, (int64_t)(win_first * hpw), (int64_t)(win_count * hpw), d_out, out_stride,
                     (int64_t)(win_first * wout), s, true);
+} catch (...) {
+    return rc_catch();
 }
 
 int rc_engine_stretch_device(rc_engine *e, const float *d_in, size_t in_stride, size_t in_len,
                              float *d_out, size_t out_stride, size_t out_cap, size_t *out_len,
-                             void *hip_stream) {
+                             void *hip_stream) try {
     if (!e) return fail(RC_EINVAL, "null engine");
     const uint64_t total_win = offline_windows(e->par, in_len);
     int rc = rc_engine_stretch_device_range(e, d_in, in_stride, in_len, 0, e->cfg.channels, 0,
                                             total_win, d_out, out_stride, out_cap, hip_stream);
     if (rc == RC_OK && out_len) *out_len = (size_t)(total_win * e->par.window_out_len);
     return rc;
+} catch (...) {
+    return rc_catch();
 }
 
 int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, float *const *out,
-                           size_t out_cap, size_t *out_len) {
+                           size_t out_cap, size_t *out_len) try {
     if (!e || !in || !out) return fail(RC_EINVAL, "null argument");
     int rc = check_gpu_path(e);
     if (rc) return rc;
@@ -1073,6 +1097,8 @@ int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, 
     RC_HIP(hipStreamSynchronize(e->stream));
     if (out_len) *out_len = n_out;
     return RC_OK;
+} catch (...) {
+    return rc_catch();
 }
 
 int rc_engine_synchronize(rc_engine *e) {
@@ -1094,7 +1120,7 @@ int rc_engine_last_kernel_stats(rc_engine *e, float *kernel_ms, uint64_t *hops, 
     return RC_OK;
 }
 
-int rc_engine_forward_fft(rc_engine *e, const float *samples, float *out_reim) {
+int rc_engine_forward_fft(rc_engine *e, const float *samples, float *out_reim) try {
     if (!e || !samples || !out_reim) return fail(RC_EINVAL, "null argument");
     const uint32_t N = e->par.window_len;
     RC_HIP(hipSetDevice(e->device));
@@ -1118,9 +1144,11 @@ int rc_engine_forward_fft(rc_engine *e, const float *samples, float *out_reim) {
     RC_HIP(hipMemcpyAsync(out_reim, e->d_hop_out.p, (size_t)N * 2 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     RC_HIP(hipStreamSynchronize(e->stream));
     return RC_OK;
+} catch (...) {
+    return rc_catch();
 }
 
-int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float *samples, float *out) {
+int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float *samples, float *out) try {
     if (!e || !samples || !out) return fail(RC_EINVAL, "null argument");
     const uint32_t N = e->par.window_len;
     RC_HIP(hipSetDevice(e->device));
@@ -1157,6 +1185,8 @@ int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float 
     RC_HIP(hipMemcpyAsync(out, e->d_ybuf.p, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     RC_HIP(hipStreamSynchronize(e->stream));
     return RC_OK;
+} catch (...) {
+    return rc_catch();
 }
 
 }  // extern "C"
