@@ -174,6 +174,7 @@ struct rc_engine {
     // seam hand-over between the runs of hop3_kernel (HopParams::seam_*): stash [runs][H], one flag
     // per run (compared with seam_epoch, so it is zeroed only when it is (re)allocated), run counter
     DevBuf d_seam_head, d_seam_flag, d_run_counter;
+    DevBuf d_tail_stage;  // large windows: tails written by big_cr_kernel, copied to d_tail after the launch
     uint32_t seam_epoch = 0;
     std::vector<float> h_spec, h_spec2, h_io;
     bool tail_zeroed = false;
@@ -589,7 +590,35 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         } else {
             plan_runs(e, n_channels, kc, &q.runs_per_channel, &q.run_len);
         }
-        if (big && !e->cfg.kernel) {
+#ifndef RC_BIGCR
+#define RC_BIGCR 1
+#endif
+        if (RC_BIGCR && big && !e->cfg.kernel && e->cfg.pitch_multiple >= 1) {
+            // stage C with the overlap-add fused: runs of hops per quarter, tail in registers; the
+            // tail of the chunk's last hop goes to a staging buffer and replaces d_tail afterwards
+            // (the first run of this very launch still reads the old one)
+            if ((rcc = e->d_tail_stage.reserve((size_t)e->cfg.channels * H * sizeof(float)))) return rcc;
+            RC_HIP(rc::launch_big(0, b, s));
+            RC_HIP(rc::launch_big(1, b, s));
+            rc::BigOlaParams c{};
+            c.b = b;
+            c.out = d_out;
+            c.out_stride = out_stride;
+            c.out_origin = out_origin;
+            c.env = e->d_env;
+            c.amp = e->par.corrected_amp_factor;
+            c.pitch = (uint32_t)e->cfg.pitch_multiple;
+            c.tail_in = (const float *)e->d_tail.p + (size_t)ch_first * H;
+            c.tail_out = (float *)e->d_tail_stage.p + (size_t)ch_first * H;
+            c.run_len = 16;
+            c.runs = (uint32_t)((kc + c.run_len - 1) / c.run_len);
+            c.tail_only = tail_only ? 1u : 0u;
+            RC_HIP(rc::launch_big_cr(c, s));
+            RC_HIP(hipMemcpyAsync((float *)e->d_tail.p + (size_t)ch_first * H, c.tail_out,
+                                  (size_t)n_channels * H * sizeof(float), hipMemcpyDeviceToDevice, s));
+            launches += 3;
+            return RC_OK;
+        } else if (big && !e->cfg.kernel) {
             for (int stage = 0; stage < 3; ++stage) RC_HIP(rc::launch_big(stage, b, s));
             launches += 3;
         } else {
@@ -902,6 +931,7 @@ void rc_engine_destroy(rc_engine *e) {
     e->d_seam_head.release();
     e->d_seam_flag.release();
     e->d_run_counter.release();
+    e->d_tail_stage.release();
     for (int i = 0; i < 2; ++i) {
         e->kp.d_spec[i].release();
         e->kp.d_ybuf[i].release();

@@ -97,6 +97,23 @@ struct BigParams {
     uint32_t log2n;          // 15 or 16
 };
 
+// Stage C of the large-window pipeline with the overlap-add fused (pitch >= 1, no user kernel): a
+// workgroup walks a run of hops of one quarter and carries y_{k-1}[H..] in registers, so y never
+// goes to HBM and the gather-form ola_kernel is not needed.
+struct BigOlaParams {
+    BigParams b;
+    float *out;             // F, channel c at out + c * out_stride
+    size_t out_stride;
+    int64_t out_origin;
+    const float *env;       // [N/2]
+    float amp;
+    uint32_t pitch;
+    const float *tail_in;   // [n_channels][N/2]: y_{hop_first-1}[H..] (read by the first run)
+    float *tail_out;        // [n_channels][N/2]: y_{last}[H..]       (written by the last run)
+    uint32_t run_len, runs; // hops [r * run_len, ...) of the chunk per run
+    uint32_t tail_only;     // 1: compute tails only, store nothing to out
+};
+
 enum HopMode { MODE_FUSED = 0, MODE_FORWARD = 1, MODE_RESYNTH = 2 };
 
 // Geometry chosen by the kernels for a window length (threads per workgroup, LDS bytes).
@@ -111,5 +128,6 @@ hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only = false)
 // stage 0 = A (forward quarter FFTs), 1 = B (radix-4 + middle + radix-4), 2 = C (inverse quarter FFTs)
 // mode selects stage B's variant (user-kernel path: MODE_FORWARD, host apply(), MODE_RESYNTH)
 hipError_t launch_big(int stage, const BigParams &p, hipStream_t s, HopMode mode = MODE_FUSED);
+hipError_t launch_big_cr(const BigOlaParams &p, hipStream_t s);
 
 }  // namespace rc

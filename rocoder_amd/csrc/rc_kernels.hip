@@ -1982,6 +1982,110 @@ __global__ __launch_bounds__(Geo<LOG2NS>::T, 2) void big_c_kernel(const BigParam
     }
 }
 
+// Stage C + overlap-add (BigOlaParams): thread t's register q is complex sample n' = t + T q of
+// quarter `sub`, i.e. floats i0 = 2 (4 n' + sub), i0 + 1 of y_k; q < 16 is the head, q + 16 the
+// matching tail sample (i0 + N/2), so the two-term overlap-add runs in registers as in the fused
+// kernels. The hop before a run is recomputed for its tail (its U_s is in the scratch of the chunk);
+// the first run of a chunk reads the tail the previous chunk left.
+template <int LOG2NS>
+__global__ __launch_bounds__(Geo<LOG2NS>::T, 2) void big_cr_kernel(const BigOlaParams pp) {
+    using G = Geo<LOG2NS>;
+    constexpr int P = G::P, T = G::T, Ms = G::M, PH = P / 2;
+    constexpr int LL = last_lor<G>(G::m);
+    static_assert(LL == 0 && G::B == 5 && P == 32, "thread t holds positions 32 t + q");
+    constexpr int RS = 33 * T / 32;
+    constexpr int H = 4 * Ms;  // floats per half window
+    const BigParams &p = pp.b;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    ThreadCtx<G> ctx;
+    ctx.tid = threadIdx.x;
+    fill_lds_bases<G, G::m>(ctx);
+    const int tid = ctx.tid;
+    uint32_t sub;
+    int64_t run;
+    big_block(blockIdx.x, sub, run);
+    if (run >= (int64_t)pp.runs) return;
+    const uint32_t ch = blockIdx.y;
+    const int64_t k_first = run * (int64_t)pp.run_len;
+    const int64_t k_last = k_first + pp.run_len < p.hop_count ? k_first + pp.run_len : p.hop_count;
+    GF win = (GF)p.window;
+    GF env = (GF)pp.env;
+    GFW outc = (GFW)pp.out + (size_t)ch * pp.out_stride;
+    float2 tail[PH];
+    if (run == 0) {
+        GF tin = (GF)pp.tail_in + (size_t)ch * H;
+#pragma unroll
+        for (int q = 0; q < PH; ++q) {
+            const int i0 = 2 * (4 * (tid + T * q) + (int)sub);
+            tail[q] = make_float2(tin[i0], tin[i0 + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < PH; ++q) tail[q] = make_float2(0.f, 0.f);
+    }
+    Stamps st;
+    st.init();
+    for (int64_t hl = run == 0 ? k_first : k_first - 1; hl < k_last; ++hl) {
+        const size_t hop_idx = (size_t)ch * p.hop_count + (size_t)hl;
+        GV2 u = (GV2)p.ysub + (hop_idx * 4 + sub) * Ms;
+        float2 v[P];
+        int t2 = tid;
+        opaque(t2);  // addresses are recomputed per hop instead of being hoisted into live registers
+#pragma unroll
+        for (int q = 0; q < P; ++q) v[q] = ldg2(u + t2 + T * brev_c(q, 5));
+        {
+            const int wrow = big_row<G>(big_brev_tid<G>(tid));
+#pragma unroll
+            for (int q = 0; q < P; ++q) lds[RS * q + wrow] = v[q];
+            __syncthreads();
+            const int rrow = big_row<G>(tid);
+#pragma unroll
+            for (int q = 0; q < P; ++q) v[q] = lds[RS * q + rrow];
+            __syncthreads();
+        }
+        inverse_passes<G, G::m>(v, lds, ctx, (GV2)p.wtab_sub, st);
+        GF wsrc = per_hop(p.window);
+#pragma unroll
+        for (int q = 0; q < P; ++q) {  // table loads in groups of 8 (all 64 at once would spill)
+            const int i0 = 2 * (4 * (t2 + T * q) + (int)sub);
+            v[q] = make_float2(v[q].x * wsrc[i0], v[q].y * wsrc[i0 + 1]);
+            if ((q & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (hl >= k_first && !pp.tail_only) {
+            const int64_t g0 = (p.hop_first + hl) * (int64_t)H;
+            GF esrc = per_hop(pp.env);
+#pragma unroll
+            for (int q = 0; q < PH; ++q) {
+                if ((q & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+                const int i0 = 2 * (4 * (t2 + T * q) + (int)sub);
+                // same operation order as ola_kernel / src/stretcher.rs:97-100
+                const float o0 = (v[q].x + tail[q].x) * esrc[i0] * pp.amp;
+                const float o1 = (v[q].y + tail[q].y) * esrc[i0 + 1] * pp.amp;
+                const int64_t g = g0 + i0;
+                if (pp.pitch == 1) {
+                    stg2((GV2W)(outc + (g - pp.out_origin)), make_float2(o0, o1));
+                } else {
+                    if (g % pp.pitch == 0) outc[g / pp.pitch - pp.out_origin] = o0;
+                    if ((g + 1) % pp.pitch == 0) outc[(g + 1) / pp.pitch - pp.out_origin] = o1;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PH; ++q) tail[q] = v[q + PH];
+        __syncthreads();  // the exchange buffer is free again
+    }
+    (void)win;
+    (void)env;
+    if (run + 1 == (int64_t)pp.runs) {
+        GFW tout = (GFW)pp.tail_out + (size_t)ch * H;
+#pragma unroll
+        for (int q = 0; q < PH; ++q) {
+            const int i0 = 2 * (4 * (tid + T * q) + (int)sub);
+            stg2((GV2W)(tout + i0), tail[q]);
+        }
+    }
+}
+
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmuli(float2 a) { return make_float2(-a.y, a.x); }    // * (+i)
@@ -2141,6 +2245,19 @@ hipError_t launch_big(int stage, const BigParams &p, hipStream_t s, HopMode mode
     }
     // quarter FFT of N/8 complex points == the passes of window length N/4
     return p.log2n == 15 ? launch_big_ac<13>(stage, p, s) : launch_big_ac<14>(stage, p, s);
+}
+
+hipError_t launch_big_cr(const BigOlaParams &p, hipStream_t s) {
+    if (p.b.log2n != 15 && p.b.log2n != 16) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((p.runs + 7) / 8 * 32), p.b.n_channels);
+    if (p.b.log2n == 15) {
+        using G = Geo<13>;
+        hipLaunchKernelGGL((big_cr_kernel<13>), grid, dim3(G::T), sizeof(float2) * G::LDS_FLOAT2, s, p);
+    } else {
+        using G = Geo<14>;
+        hipLaunchKernelGGL((big_cr_kernel<14>), grid, dim3(G::T), sizeof(float2) * G::LDS_FLOAT2, s, p);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only) {
