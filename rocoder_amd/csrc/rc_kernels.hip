@@ -826,7 +826,7 @@ __device__ __forceinline__ GF hop_src(const HopParams &p, GF xc, GF xt, int64_t 
 }
 
 // =============================== v2 fused kernel (N = 16384) =================================
-// Same math as hop_kernel<.., MODE_FUSED>, restructured so that (tools/proto_v2.py is the index
+// Same math as hop_kernel<.., MODE_FUSED>, restructured so that (tests/dev/proto_v2.py is the index
 // model):
 //   * BOTH transforms are DIT (3 packed FMAs per butterfly). The forward transform's bit-reversed
 //     input order costs nothing: it is the order in which the thread's registers are loaded.

@@ -14,7 +14,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, __file__.rsplit("/", 2)[0])
+sys.path.insert(0, __file__.rsplit("/", 3)[0])
 from oracle import oracle_np as onp  # noqa: E402
 
 
