@@ -455,6 +455,28 @@ def test_16384_runs_seams_and_ranges_bit_exact(p):
     assert_parity(got, ref, f"prefix p={p}")
 
 
+def test_16384_seam_buffers_across_job_sizes():
+    """One engine, jobs of growing and shrinking size back to back: the seam stash / flags are
+    reallocated (flags cleared, epoch restarted) or reused with a new epoch; every result must equal the
+    one a fresh engine gives."""
+    import torch
+
+    ra = _engine_mod()
+    lengths = [600_000, 2_000_000, 300_000, 2_000_000, 900_000]
+    x = np.stack([onp.synth_input(c, max(lengths)) for c in range(2)])
+    xt = torch.from_numpy(x).cuda()
+    with ra.Engine(window_len=16384, factor=8.0, channels=2, seed=21) as e:
+        got = []
+        for L in lengths:
+            got.append(e.stretch_tensor(xt[:, :L].contiguous()).clone())
+        torch.cuda.synchronize()
+    for L, g in zip(lengths, got):
+        with ra.Engine(window_len=16384, factor=8.0, channels=2, seed=21) as e2:
+            ref = e2.stretch_tensor(xt[:, :L].contiguous())
+            torch.cuda.synchronize()
+            assert torch.equal(g, ref), f"L={L}"
+
+
 def test_large_window_ranges_concatenate_to_full_output():
     import torch
 
