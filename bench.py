@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the stretch hot path on MI355X.
 
-A "step" is one whole pass of the hot path over one synthetic job already resident in HBM:
-BASELINE.json configs[1] — stereo 44.1 kHz, window 16384, factor 8, pitch 1, L = 26 460 000
-samples per channel (600 s), i.e. 51 652 hops -> 423 133 184 output samples per step.
-`value` = whole-job output Msamples/s over all ranks (weak scaling: every rank stretches its own
-stereo job; channels/hop ranges are independent, there is no data-path collective).
+A "step" is one whole pass of the hot path over one synthetic job already resident in HBM. At N = 1 the
+job is BASELINE.json configs[1] — stereo 44.1 kHz, window 16384, factor 8, pitch 1, L = 26 460 000
+samples per channel (600 s): 51 652 hops -> 423 133 184 output samples per step. At N > 1 it is ONE
+stereo job of N x L samples per channel cut by rocoder_amd.distributed.shard_plan into (channel, hop
+range) shards, one rank per GPU (N = 2: a channel per GPU; N = 4, 8: half / quarter channels; every
+rank recomputes the single hop before its range): per-GPU work is that of N = 1 (weak scaling) and the
+data path has no collective. `value` = output samples of all ranks / max-rank time of the timed steps,
+outputs left sharded in HBM; the cost of the one optional collective, the RCCL concat of the shards on
+rank 0, is measured in a second timed region and reported beside it (config.concat).
 
 The same JSON line carries
-  roofline     — the dominant kernel (rc::hop3_kernel, the N=16384 fused hop kernel) priced on SURVEY §8(d4)'s
-                 algorithmic READ bytes 4*N per hop against the 8 TB/s HBM peak, its launch duration
-                 measured live with events on the stream it is launched on;
-  cpu_baseline — the CPU restatement of the reference algorithm (oracle/rocoder_oracle.c, "port":
-                 the Rust reference cannot be built here) on a bounded sample of the same workload,
-                 1 DSP thread as in src/stretcher_processor.rs:55-71 — rank 0, N=1 only.
+  roofline     — the dominant kernel (the N = 16384 fused hop kernel) priced on SURVEY §8(d4)'s
+                 algorithmic READ bytes 4*N per hop against the 8 TB/s HBM peak; its duration is the
+                 MEDIAN of the per-launch HIP-event times the engine records around the kernel itself
+                 (rc_engine_kernel_times), after >= 2 s of back-to-back launches (steady clocks);
+                 also against the copy bandwidth measured on this very device, and the total-traffic,
+                 compulsory and LDS-traffic figures of SURVEY §8 d3/d4;
+  cpu_baseline — the CPU path of the reference algorithm written for speed (oracle/
+                 rocoder_cpu_baseline.c, "port": the Rust reference cannot be built here), one DSP thread
+                 as in src/stretcher_processor.rs:55-71, on a bounded sample of the same workload;
+  cpu_baseline_all_cores — the same code on every core this process may use (rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,7 +41,9 @@ CHANNELS = 2
 SAMPLE_RATE = 44100
 L_IN = 26_460_000
 SEED = 0x5EED
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+LDS_READ_PEAK_GBS = 150e3    # MI355X_MICROARCH.md §LDS: ds_read_b64/b128, every CU streaming
+LDS_WRITE_PEAK_GBS = 45e3    # same: 38-51 TB/s for ds_write_b32..b128
 
 
 def synth_on_device(torch, device, channels, length):
@@ -41,66 +52,87 @@ def synth_on_device(torch, device, channels, length):
     depend on the noise bits)."""
     g = torch.Generator(device=device)
     g.manual_seed(0xC0DEC0DE)
-    t = torch.arange(length, device=device, dtype=torch.float64) / SAMPLE_RATE
     rows = []
     for c in range(channels):
+        t = torch.arange(length, device=device, dtype=torch.float64) / SAMPLE_RATE
         s = 0.5 * torch.sin(2 * torch.pi * 220.0 * (c + 1) * t)
+        del t
         u = torch.rand(length, device=device, generator=g, dtype=torch.float64) * 2 - 1
         rows.append((s + 0.05 * u).to(torch.float32))
+        del s, u
     return torch.stack(rows).contiguous()
 
 
-def pmc_traffic():
+def pmc_traffic(kernel_id):
     """HBM-side bytes per hop-kernel launch from the committed rocprofv3 PMC passes of this same
     command (profiles/, separate --pmc runs: FETCH_SIZE, WRITE_SIZE in KiB). Per
     MI355X_MICROARCH.md §HBM, FETCH_SIZE on gfx950 tallies 128-B read requests at 64 B, so the read
-    side is doubled; WRITE_SIZE is exact. Returns (bytes, source) or (None, None)."""
+    side is doubled; WRITE_SIZE is exact. Only a summary that names the kernels this library holds
+    (`kernel_id:` line) is quoted: counters of an older kernel say nothing about this one.
+    Returns (bytes, source) or (None, reason)."""
     import glob
     import re
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
-    if not files:
-        return None, None
-    txt = open(files[-1]).read()
-    f = re.search(r"FETCH_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt)
-    w = re.search(r"WRITE_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt)
-    if not (f and w):
-        return None, None
-    return (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0, os.path.relpath(files[-1], ROOT)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")), reverse=True):
+        txt = open(path).read()
+        kid = re.search(r"^#?\s*kernel_id:\s*(\S+)", txt, re.M)
+        if not kid or kid.group(1) != kernel_id:
+            continue
+        f = re.search(r"FETCH_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt)
+        w = re.search(r"WRITE_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt)
+        if f and w:
+            return (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0, os.path.relpath(path, ROOT)
+    return None, f"no profiles/r*_pmc_summary.txt for kernel_id {kernel_id}"
 
 
-def cpu_baseline():
-    """Time the oracle (a port of the reference algorithm, 1 thread for all channels) on a bounded
-    sample: stereo, L = 15 000 000 per channel, same window/factor -> ~240 M output samples
-    (about 15 s of CPU work)."""
+def cpu_baselines(all_cores=True):
+    """Time oracle/rocoder_cpu_baseline.c (the reference's per-hop work with an optimised FFT) on
+    bounded samples of the workload: one thread for all channels, then every core available."""
     import numpy as np
 
     from oracle import cbind as oc
     from oracle import oracle_np as onp
 
-    length = 15_000_000
-    x = np.stack([onp.synth_input(c, length) for c in range(CHANNELS)])
-    t0 = time.perf_counter()
-    y = oc.stretch_offline(x, WINDOW, FACTOR, 1.0, PITCH, seed=SEED, sample_rate=SAMPLE_RATE)
-    dt = time.perf_counter() - t0
-    return {
-        "value": round(y.size / dt / 1e6, 3),
-        "unit": "Msamples/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"stereo L={length}/ch window={WINDOW} factor={FACTOR:g} -> {y.size} output samples "
-                  f"in {dt:.1f}s; C restatement of rocoder's algorithm (oracle/), scalar libm, one DSP "
-                  f"thread for all channels like src/stretcher_processor.rs:55-71; host has "
-                  f"{os.cpu_count()} logical cores",
+    def run(length, threads):
+        x = np.stack([onp.synth_input(c, length) for c in range(CHANNELS)])
+        t0 = time.perf_counter()
+        y = oc.cpu_baseline_stretch(x, WINDOW, FACTOR, 1.0, PITCH, seed=SEED, threads=threads)
+        dt = time.perf_counter() - t0
+        return y.size, dt
+
+    what = ("CPU path of rocoder's algorithm written for speed (oracle/rocoder_cpu_baseline.c: full N-point "
+            "complex FFTs as src/fft.rs:59,69 with a radix-4 Stockham FFT, scalar libm hypotf/sincosf per bin "
+            "as src/fft.rs:65-68), not the rocoder binary (no Rust toolchain)")
+    n1, t1 = run(8_000_000, 1)
+    one = {
+        "value": round(n1 / t1 / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+        "sample": f"stereo L=8000000/ch window={WINDOW} factor={FACTOR:g} -> {n1} output samples in {t1:.1f}s; "
+                  f"one DSP thread for all channels like src/stretcher_processor.rs:55-71; {what}",
     }
+    many = None
+    if all_cores:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = max(1, min(cores, 64))
+        length = 8_000_000 if cores < 8 else 24_000_000
+        nm, tm = run(length, cores)
+        many = {
+            "value": round(nm / tm / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"stereo L={length}/ch -> {nm} output samples in {tm:.1f}s; OpenMP, one task per (channel, "
+                      f"hop range), the hop before a range recomputed; host reports {os.cpu_count()} logical cores",
+        }
+    return one, many
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preheat-s", type=float, default=2.0,
+                    help="seconds of back-to-back launches before the timed steps (steady DVFS state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the copy microbench, the PCIe-inclusive run and the concat region")
     args = ap.parse_args()
 
     # Exactly ONE line on stdout (the JSON): RCCL / the HIP runtime print banners to fd 1, so park
@@ -127,14 +159,29 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import rocoder_amd
+    from rocoder_amd import _lib
+    from rocoder_amd.distributed import engine_compute, shard_plan, shard_view, stretch_sharded
 
+    kernel_id = _lib.lib().rc_kernel_id().decode()
+    # ONE job for all ranks: same seed, same (replicated, device-generated) input of world x L samples
+    length = L_IN * world
     eng = rocoder_amd.Engine(window_len=WINDOW, factor=FACTOR, pitch_multiple=PITCH,
-                             sample_rate=SAMPLE_RATE, channels=CHANNELS, seed=SEED + rank,
-                             device=local_rank)
-    x = synth_on_device(torch, device, CHANNELS, L_IN)
-    n_out = eng.output_len(L_IN)
-    out = torch.empty((CHANNELS, n_out), dtype=torch.float32, device=device)
-    hops_per_step = (n_out * PITCH // (WINDOW // 2)) * CHANNELS
+                             sample_rate=SAMPLE_RATE, channels=CHANNELS, seed=SEED, device=local_rank)
+    x = synth_on_device(torch, device, CHANNELS, length)
+    wout = eng.params.window_out_len
+    n_out = eng.output_len(length)          # per channel, whole job
+    nwin = n_out // wout
+    plan = shard_plan(CHANNELS, nwin, world)
+    mine = [s for s in plan if s.rank == rank]
+    compute = engine_compute(eng, x)
+    # this rank's shards stay in its own HBM (no collective in the timed steps)
+    bufs = {s: torch.empty((s.ch_count, s.win_count * wout), dtype=torch.float32, device=device) for s in mine}
+    my_samples = sum(b.numel() for b in bufs.values())
+    hops_mine = my_samples * PITCH // (WINDOW // 2)
+
+    def step():
+        for s in mine:
+            compute(s, out=bufs[s])
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -142,35 +189,135 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    # a real (non-default) stream: the engine launches its kernel on exactly this stream, and the
-    # events below are recorded on it, so they bracket the hop-kernel launches
+    # a real (non-default) stream: the engine launches its kernels on exactly this stream
     stream = torch.cuda.Stream(device)
     barrier()
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
-            eng.stretch_tensor(x, out=out)
+            step()
+        # pre-heat: >= preheat_s of back-to-back launches so the timed steps run at the clock the chip
+        # holds under this load (MI355X_MICROARCH.md, DVFS), not at the boost clock of an idle chip
+        t_heat = time.perf_counter()
+        n_heat = 0
+        while time.perf_counter() - t_heat < args.preheat_s:
+            for _ in range(32):
+                step()
+            n_heat += 32
+            stream.synchronize()
         barrier()
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
         for _ in range(args.steps):
-            eng.stretch_tensor(x, out=out)
+            step()
         ev1.record(stream)
         barrier()
         dt = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # per launch (one hop-kernel launch per step)
+        step_event_ms = ev0.elapsed_time(ev1) / args.steps
+        # per-launch kernel durations of exactly those steps (the engine brackets each kernel launch)
+        per_call = eng.kernel_times(min(64, args.steps * max(1, len(mine))))
+        kernel_ms_median = statistics.median(per_call)
+        kernel_ms_mean = sum(per_call) / len(per_call)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    extras = {}
+    concat = None
+    if not args.no_extras:
+        with torch.cuda.stream(stream):
+            # device copy microbench on this very GPU: the measured bandwidth the roofline is also priced on
+            n_copy = 1 << 28  # 1 GiB of f32
+            a = torch.empty(n_copy, dtype=torch.float32, device=device).normal_()
+            b = torch.empty_like(a)
+            for _ in range(3):
+                b.copy_(a)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record(stream)
+            for _ in range(10):
+                b.copy_(a)
+            c1.record(stream)
+            stream.synchronize()
+            extras["copy_GBs"] = 2.0 * 4.0 * n_copy * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+            del a, b
+            if dist is not None and world > 1:
+                # the one collective of the path: concat of the shards on rank 0, straight into the final
+                # layout (stretch_sharded). Timed as compute + concat per step.
+                full = torch.empty((CHANNELS, n_out), dtype=torch.float32, device=device) if rank == 0 else None
+                k2 = max(2, min(5, args.steps))
+                stretch_sharded(compute, CHANNELS, nwin, wout, dst=0, full=full)
+                barrier()
+                tc = time.perf_counter()
+                for _ in range(k2):
+                    stretch_sharded(compute, CHANNELS, nwin, wout, dst=0, full=full)
+                barrier()
+                dtc = time.perf_counter() - tc
+                tt = torch.tensor([dtc], dtype=torch.float64, device=device)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dtc = float(tt.item())
+                concat = {
+                    "steps": k2,
+                    "ms_per_step_with_concat": round(dtc / k2 * 1e3, 4),
+                    "value_with_concat": round(float(n_out) * CHANNELS * k2 / dtc / 1e6, 1),
+                    "bytes_moved_to_rank0": int((n_out * CHANNELS - (my_samples if rank == 0 else 0)) * 4),
+                    "how": "grouped RCCL send/recv of each shard into its view of the final [channels, n_out] "
+                           "tensor on rank 0 (root-inbound-bound); no pad, no staging copy",
+                }
+                del full
+        if world == 1:
+            # PCIe-inclusive (host buffers in and out): never `value`, reported for SURVEY §8 d1
+            xh = x.cpu().numpy()
+            t_e = time.perf_counter()
+            yh = eng.stretch_host(xh)
+            extras["e2e_pcie_Msamples_s"] = yh.size / (time.perf_counter() - t_e) / 1e6
+            del xh, yh
+
     if rank == 0:
-        total_samples = float(n_out) * CHANNELS * args.steps * world
+        total_samples = float(n_out) * CHANNELS * args.steps
         value = total_samples / dt / 1e6
-        algo_bytes = hops_per_step * 4.0 * WINDOW  # 4N read bytes per hop
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic()
+        H = WINDOW // 2
+        step_len = eng.params.sample_step_len
+        read_b, write_b = 4.0 * WINDOW, 4.0 * H / PITCH
+        algo_bytes = hops_mine * read_b  # 4N read bytes per hop, one launch of this rank
+        sec = kernel_ms_median * 1e-3
+        achieved = algo_bytes / sec / 1e9
+        traffic, traffic_src = pmc_traffic(kernel_id)
+        # LDS bytes per hop: four exchanges of N/2 complex points (8 B each), written once and read once
+        lds_w = lds_r = 4 * (WINDOW // 2) * 8.0
+        roof = {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "kernel": f"N=16384 fused hop kernel ({kernel_id})",
+            "kernel_id": kernel_id,
+            "kernel_ms": round(kernel_ms_median, 4),
+            "kernel_ms_mean": round(kernel_ms_mean, 4),
+            "kernel_ms_min": round(min(per_call), 4),
+            "kernel_ms_max": round(max(per_call), 4),
+            "kernel_launches_timed": len(per_call),
+            "step_event_ms": round(step_event_ms, 4),
+            "preheat_launches": n_heat,
+            "hops_per_s": round(hops_mine / sec, 1),
+            "algorithmic_bytes_per_launch": algo_bytes,
+            "frac_total_traffic": round(hops_mine * (read_b + write_b) / sec / 1e9 / HBM_PEAK_GBS, 4),
+            "frac_compulsory": round(hops_mine * (4.0 * step_len + write_b) / sec / 1e9 / HBM_PEAK_GBS, 4),
+            "lds_GBs": round(hops_mine * (lds_w + lds_r) / sec / 1e9, 1),
+            "lds_time_frac": round(hops_mine * (lds_w / (LDS_WRITE_PEAK_GBS * 1e9) + lds_r / (LDS_READ_PEAK_GBS * 1e9)) / sec, 4),
+            "note": "achieved = algorithmic READ bytes 4*N per hop (SURVEY §8 d4) / median per-launch kernel time; "
+                    "frac_total_traffic adds the 4*H/p write bytes, frac_compulsory counts each input sample once "
+                    "(4*step + 4*H/p); lds_time_frac = LDS exchange bytes priced at the measured LDS store/load rates "
+                    "of MI355X_MICROARCH.md. The kernel is VALU-pipe bound (FFT butterflies + per-bin hash/sincos), "
+                    "see DESIGN.md §5",
+        }
+        if "copy_GBs" in extras:
+            roof["measured_copy_GBs"] = round(extras["copy_GBs"], 1)
+            roof["frac_measured_peak"] = round(achieved / extras["copy_GBs"], 4)
         res = {
             "metric": "output Msamples/s, 16384-win f=8 stereo (x CPU-realtime in config)",
             "value": round(value, 1),
@@ -185,34 +332,29 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: stereo 44.1 kHz, window=16384, factor=8, pitch=1, "
-                            "L=26460000/ch, inputs resident in HBM",
-                "hops_per_step": hops_per_step,
+                "workload": f"BASELINE configs[1]: stereo 44.1 kHz, window=16384, factor=8, pitch=1, "
+                            f"L={length}/ch ({world} x 26460000), inputs resident in HBM",
+                "hops_per_step": hops_mine * world,
+                "hops_per_rank": hops_mine,
                 "output_samples_per_step": n_out * CHANNELS,
-                "x_realtime": round(value * 1e6 / CHANNELS / SAMPLE_RATE / world, 1),
-                "parallelism": f"{world} rank(s), one stereo job per GPU, no data-path collective",
+                "x_realtime": round(value * 1e6 / CHANNELS / SAMPLE_RATE, 1),
+                "parallelism": (f"{world} rank(s): one job cut into (channel, hop range) shards by shard_plan "
+                                f"{[(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan]}, "
+                                "outputs left sharded in HBM, no data-path collective"),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "kernel": "rc::hop3_kernel<pitch1> (N=16384 fused hop kernel, 3 workgroups/CU)",
-                "kernel_ms": round(kernel_ms, 4),
-                "hops_per_s": round(hops_per_step / (kernel_ms * 1e-3), 1),
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "note": "algorithmic READ bytes 4*N per hop (SURVEY §8 d4); the kernel is VALU-pipe bound "
-                        "(FFT butterflies + per-bin hash/sincos: VALU busy 77 %) with LDS-exchange "
-                        "synchronisation on top, see DESIGN.md §5",
-            },
+            "roofline": roof,
         }
+        if concat:
+            res["config"]["concat"] = concat
+        if "e2e_pcie_Msamples_s" in extras:
+            res["config"]["e2e_pcie_Msamples_s"] = round(extras["e2e_pcie_Msamples_s"], 1)
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline()
-            res["cpu_baseline"] = cb
-            res["config"]["x_cpu"] = round(value / cb["value"], 1)
+            one, many = cpu_baselines()
+            res["cpu_baseline"] = one
+            res["config"]["x_cpu"] = round(value / one["value"], 1)
+            if many:
+                res["cpu_baseline_all_cores"] = many
+                res["config"]["x_cpu_all_cores"] = round(value / many["value"], 1)
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if dist is not None:
         dist.barrier()

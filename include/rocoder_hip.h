@@ -83,6 +83,9 @@ typedef struct rc_engine rc_engine;
 /* Thread-local description of the last failure on this thread. */
 const char *rc_last_error(void);
 int rc_abi_version(void);
+/* Identifies the kernel generation inside the library (e.g. "hop4/r02b"): measurement files under
+ * profiles/ carry it, so a counter summary is only ever quoted next to the kernels it was taken on. */
+const char *rc_kernel_id(void);
 /* Number of usable gfx950 devices (0 when none; never fails). */
 int rc_device_count(void);
 
@@ -127,7 +130,9 @@ int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, 
                            size_t out_cap, size_t *out_len);
 /* Same job on DEVICE-resident buffers (channel c at base + c*stride, strides in floats).
  * `hip_stream` is a hipStream_t (NULL = the engine's own stream); the call is asynchronous
- * on that stream unless a user kernel is configured. */
+ * on that stream unless a user kernel is configured. The engine's scratch (tail copy, seam stash,
+ * pipeline buffers) is per handle: a call on a different stream than the previous one first waits
+ * (on the device) for that call's last enqueue, so back-to-back calls never overlap on the GPU. */
 int rc_engine_stretch_device(rc_engine *e, const float *d_in, size_t in_stride, size_t in_len,
                              float *d_out, size_t out_stride, size_t out_cap, size_t *out_len,
                              void *hip_stream);
@@ -140,7 +145,9 @@ int rc_engine_stretch_device_range(rc_engine *e, const float *d_in, size_t in_st
                                    size_t out_stride, size_t out_cap, void *hip_stream);
 
 /* Blocks until everything the engine queued on ITS OWN stream has finished (calls that were given
- * a caller stream are ordered by that stream instead). */
+ * a caller stream are ordered by that stream instead). Like every entry point that touches the
+ * device it returns RC_EHIP, once, if an earlier launch left a device error word (a run-seam wait of
+ * the window-16384 kernel that expired: the affected output samples were not written). */
 int rc_engine_synchronize(rc_engine *e);
 
 /* ---- measurement ---------------------------------------------------------------------- */
@@ -148,6 +155,9 @@ int rc_engine_synchronize(rc_engine *e);
  * synchronises on the events. */
 int rc_engine_last_kernel_stats(rc_engine *e, float *kernel_ms, uint64_t *hops,
                                 uint32_t *launches);
+/* The same event time for each of the last min(cap, 64) offline calls, oldest first (a bench runs K
+ * calls back to back and reads K kernel durations afterwards); synchronises on the newest. */
+int rc_engine_kernel_times(rc_engine *e, float *ms, size_t cap, size_t *n_out);
 
 /* ---- single-hop entry points (ReFFT seam, used by parity tests) ----------------------- */
 /* ReFFT::forward_fft (src/fft.rs:50-61): host samples[window_len] -> host spectrum (re,im)*N */

@@ -19,8 +19,12 @@ FREQ_KERNEL = C.CFUNCTYPE(C.c_int, C.c_uint64, C.POINTER(C.c_float), C.POINTER(C
 RCO_OK, RCO_WOULD_BLOCK, RCO_EINVAL = 0, 1, -1
 
 
+_SO_BASE = os.path.join(_HERE, "librocoder_cpubase.so")
+
+
 def build(force: bool = False) -> str:
-    """Compile the C oracle with gcc (building the checker is not using it)."""
+    """Compile the C oracle (and the measured CPU baseline) with gcc: building the checker is not
+    using it."""
     src = os.path.join(_HERE, "rocoder_oracle.c")
     hdr = os.path.join(_HERE, "rocoder_oracle.h")
     stale = (not os.path.exists(_SO)
@@ -28,7 +32,40 @@ def build(force: bool = False) -> str:
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "librocoder_oracle.so"],
                               stdout=subprocess.DEVNULL)
+    bsrc = os.path.join(_HERE, "rocoder_cpu_baseline.c")
+    if force or not os.path.exists(_SO_BASE) or os.path.getmtime(_SO_BASE) < os.path.getmtime(bsrc):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "librocoder_cpubase.so"],
+                              stdout=subprocess.DEVNULL)
     return _SO
+
+
+_base = None
+
+
+def cpu_baseline_stretch(channels_in, window_len=16384, factor=1.0, amplitude=1.0, pitch_multiple=1,
+                         seed=0, threads=1) -> np.ndarray:
+    """oracle/rocoder_cpu_baseline.c: the reference's algorithm written for speed (optimised FFT,
+    optional OpenMP over hop ranges) - what bench.py times as `cpu_baseline`. [C, L] -> [C, n_out]."""
+    global _base
+    if _base is None:
+        build()
+        _base = C.CDLL(_SO_BASE)
+        _base.rcb_output_len.restype = C.c_size_t
+        _base.rcb_output_len.argtypes = [C.c_size_t, C.c_uint32, C.c_float, C.c_int]
+        _base.rcb_stretch.restype = C.c_int
+        _base.rcb_stretch.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_uint32, C.c_uint32, C.c_float,
+                                      C.c_float, C.c_int, C.c_uint64, C.POINTER(C.c_float), C.c_int]
+    x = np.ascontiguousarray(np.atleast_2d(channels_in), dtype=np.float32)
+    nch, length = x.shape
+    n_out = _base.rcb_output_len(length, window_len, factor, pitch_multiple)
+    if n_out == 0:
+        raise ValueError("unsupported parameters for the CPU baseline")
+    out = np.zeros((nch, n_out), np.float32)
+    rc = _base.rcb_stretch(_fp(x), length, nch, window_len, factor, amplitude, pitch_multiple, seed,
+                           _fp(out), threads)
+    if rc != 0:
+        raise ValueError(f"rcb_stretch rc={rc}")
+    return out
 
 
 _lib = None

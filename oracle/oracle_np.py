@@ -103,9 +103,28 @@ def resample(x: np.ndarray, factor: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------- one hop
+def phase_theta_independent23(key: int, bins, n_bins: int) -> np.ndarray:
+    """SURVEY §8 c5's literal form, coupled to the frozen spec: EVERY bin gets rand 0.8.5's 23-bit
+    draw, and the draws of bins b and b + n/2 share no hash bit. Bin b < n/2 keeps bits 16..31 of
+    hash(b) as the top 16 of its 23 bits, bin b + n/2 takes bits 0..15 of hash(b) as ITS top 16; the
+    low 7 bits of both come from a second, independently keyed hash. Used only by the test that prices
+    the frozen spec's two shortcuts (16-bit upper phases; bits 9..15 of hash(b) seen by both bins):
+    |theta_spec - theta_independent23| < pi 2^-16 for every bin, by construction."""
+    bins = np.asarray(bins, dtype=np.uint32)
+    half = np.uint32(n_bins // 2)
+    upper = bins >= half
+    h = phase_hash(key, np.where(upper, bins - half, bins))
+    fresh = phase_hash(_mix64(key ^ 0xA5A5A5A5DEADBEEF), bins)  # own counter per bin, other key
+    lo7 = fresh & np.uint32(0x7F)
+    u_lo = (((h >> np.uint32(16)) << np.uint32(7)) | lo7)
+    u_up = (((h & np.uint32(0xFFFF)) << np.uint32(7)) | lo7)
+    u = np.where(upper, u_up, u_lo).astype(np.float32) * np.float32(1.0 / 8388608.0)
+    return (u * PI_F32).astype(np.float32)
+
+
 def resynth(samples: np.ndarray, window: np.ndarray, key: int, kernel=None, time_ms: int = 0,
-            return_spectrum: bool = False):
-    """ReFFT::resynth (fft.rs:42-74) in f64."""
+            return_spectrum: bool = False, theta_fn=None):
+    """ReFFT::resynth (fft.rs:42-74) in f64. theta_fn (tests only) replaces phase_theta."""
     n = window.size
     a = samples[:n].astype(np.float64) * window.astype(np.float64)
     X = np.fft.fft(a)  # unnormalised, e^{-i...}: fft.rs:59
@@ -116,7 +135,7 @@ def resynth(samples: np.ndarray, window: np.ndarray, key: int, kernel=None, time
                 X = Y.astype(np.complex128)
         except Exception:
             pass  # panic -> noop (fft.rs:100-106)
-    theta = phase_theta(key, np.arange(n), n).astype(np.float64)
+    theta = (theta_fn or phase_theta)(key, np.arange(n), n).astype(np.float64)
     Z = np.abs(X) * (np.cos(theta) + 1j * np.sin(theta))  # fft.rs:65-68
     y = np.fft.ifft(Z).real  # ifft = unnormalised inverse / N  (fft.rs:69,72)
     out = y * window.astype(np.float64)

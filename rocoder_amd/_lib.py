@@ -58,6 +58,7 @@ _eng = C.c_void_p
 SYMBOLS = {
     "rc_last_error": (C.c_char_p, []),
     "rc_abi_version": (C.c_int, []),
+    "rc_kernel_id": (C.c_char_p, []),
     "rc_device_count": (C.c_int, []),
     "rc_derive_params": (C.c_int, [C.POINTER(rc_config), C.POINTER(rc_params)]),
     "rc_offline_output_len": (_sz, [C.POINTER(rc_config), _sz]),
@@ -82,6 +83,7 @@ SYMBOLS = {
     "rc_engine_synchronize": (C.c_int, [_eng]),
     "rc_engine_last_kernel_stats": (C.c_int, [_eng, C.POINTER(C.c_float), C.POINTER(C.c_uint64),
                                               C.POINTER(C.c_uint32)]),
+    "rc_engine_kernel_times": (C.c_int, [_eng, _fp, _sz, C.POINTER(_sz)]),
     "rc_engine_forward_fft": (C.c_int, [_eng, _fp, _fp]),
     "rc_engine_resynth": (C.c_int, [_eng, C.c_uint32, C.c_uint64, _fp, _fp]),
 }

@@ -158,8 +158,10 @@ struct rc_engine {
     int log2n = 0;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool stats_valid = false;
+    // event pairs around the kernel launches of the last RC_TIMING_RING offline calls (measurement)
+    static constexpr int kRing = 64;
+    hipEvent_t ev0[kRing] = {}, ev1[kRing] = {};
+    uint64_t timed_calls = 0;  // slot of call i is i % kRing
     uint64_t stats_hops = 0;
     uint32_t stats_launches = 0;
     float *d_window = nullptr, *d_env = nullptr;
@@ -176,8 +178,20 @@ struct rc_engine {
     DevBuf d_seam_head, d_seam_flag, d_run_counter;
     DevBuf d_tail_stage;  // large windows: tails written by big_cr_kernel, copied to d_tail after the launch
     uint32_t seam_epoch = 0;
+    // device -> host error word (pinned, mapped): a kernel that gives up (seam wait expired) leaves a
+    // code here; the next API call reports it as RC_EHIP
+    uint32_t *h_err = nullptr, *d_err = nullptr;
+    uint32_t diag_flags = 0;  // ROCODER_DIAG (tests only)
     std::vector<float> h_spec, h_spec2, h_io;
     bool tail_zeroed = false;
+    // user-kernel path: a stateful apply() forbids recomputing hops, so the overlap tail is carried
+    // on the device and ranges must continue where the previous one ended (or restart at hop 0)
+    std::vector<int64_t> kernel_next_hop;
+    // scratch (tail copy, seam stash, run counter, pipe buffers) is per engine: a call on another
+    // stream first waits for the previous call's last enqueue
+    hipEvent_t ev_last = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool last_valid = false;
     // user-kernel path: two chunk-sized resource sets so that the forward transform + D2H of chunk
     // i, the host apply() calls of chunk i - 1 and the H2D + resynthesis + overlap-add of chunk i - 2
     // overlap (streams kf / kb beside the caller's stream; pinned host buffers)
@@ -242,6 +256,10 @@ rc::HopParams base_params(const rc_engine *e) {
     p.step = e->par.sample_step_len;
     p.pitch = (uint32_t)std::max(1, e->cfg.pitch_multiple);
     p.seed_mixed = e->seed_mixed;
+    p.err_word = e->d_err;
+    p.diag_flags = e->diag_flags;
+    // 2^22 polls of ~2 000 cycles each (seconds); the diagnostic build of the protocol gives up at once
+    p.seam_spin_limit = (e->diag_flags & rc::RC_DIAG_SKIP_SEAM_PUBLISH) ? 64u : (1u << 22);
     return p;
 }
 
@@ -270,8 +288,14 @@ rc::BigParams big_params(const rc_engine *e, const rc::HopParams &p) {
 }
 
 
-int check_gpu_path(const rc_engine *e) {
-    (void)e;
+// A kernel that could not finish its work (HopParams::err_word) fails the NEXT call on the handle, once.
+int check_device_error(rc_engine *e) {
+    if (!e->h_err) return RC_OK;
+    const uint32_t code = __atomic_exchange_n(e->h_err, 0u, __ATOMIC_ACQ_REL);
+    if (code == rc::RC_ERR_SEAM_TIMEOUT)
+        return fail(RC_EHIP, "an earlier launch on this engine gave up waiting for a run seam hand-over: "
+                             "its output is incomplete");
+    if (code) return fail(RC_EHIP, "an earlier launch on this engine reported device error %u", code);
     return RC_OK;
 }
 
@@ -434,6 +458,25 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
              uint32_t ch_first, uint32_t n_channels, int64_t hop_first, int64_t hop_count,
              float *d_out, size_t out_stride, int64_t out_origin, hipStream_t s, bool timed) {
     if (hop_count <= 0 || n_channels == 0) return RC_OK;
+    if (e->cfg.kernel) {
+        for (uint32_t c = ch_first; c < ch_first + n_channels; ++c)
+            if (hop_first != 0 && hop_first != e->kernel_next_hop[c])
+                return fail(RC_EINVAL, "a user kernel carries the overlap tail: channel %u continues at hop %lld "
+                                       "(or restarts at 0), not at %lld", c, (long long)e->kernel_next_hop[c],
+                            (long long)hop_first);
+        for (uint32_t c = ch_first; c < ch_first + n_channels; ++c) e->kernel_next_hop[c] = hop_first + hop_count;
+    }
+    if (e->last_valid && e->last_stream != s) RC_HIP(hipStreamWaitEvent(s, e->ev_last, 0));
+    struct MarkLast {  // whatever path returns: the next call orders itself behind this one
+        rc_engine *e;
+        hipStream_t s;
+        ~MarkLast() {
+            if (hipEventRecord(e->ev_last, s) == hipSuccess) {
+                e->last_stream = s;
+                e->last_valid = true;
+            }
+        }
+    } mark_last{e, s};
     rc::HopParams p = base_params(e);
     p.x = d_in;
     p.in_stride = in_stride;
@@ -515,7 +558,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
                 p.seam_epoch = e->seam_epoch;
             }
         }
-        if (timed) RC_HIP(hipEventRecord(e->ev0, s));
+        if (timed) RC_HIP(hipEventRecord(e->ev0[e->timed_calls % rc_engine::kRing], s));
         RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FUSED, p, s));
 #ifdef RC_STAMP_DUMP
         if (const char *path = getenv("ROCODER_STAMPS")) {
@@ -539,8 +582,8 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         }
 #endif
         if (timed) {
-            RC_HIP(hipEventRecord(e->ev1, s));
-            e->stats_valid = true;
+            RC_HIP(hipEventRecord(e->ev1[e->timed_calls % rc_engine::kRing], s));
+            e->timed_calls++;
             e->stats_hops = (uint64_t)hop_count * n_channels;
             e->stats_launches = 1;
         }
@@ -558,8 +601,8 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     // streaming batches do not depend on call history.
     const bool big = e->log2n > 14;
     const uint32_t hpw = e->par.hops_per_window;
-    const size_t per_hop = (size_t)N * (big && e->cfg.kernel ? 16 : 12);  // spectrum, quarter-FFT scratch, y
-    int64_t chunk_max = (int64_t)((((size_t)(e->cfg.kernel ? 192 : 1024)) << 20) / (per_hop * n_channels));
+    const size_t per_hop = (size_t)N * 12;  // spectrum / quarter-FFT scratch, y
+    int64_t chunk_max = (int64_t)(((size_t)1024 << 20) / (per_hop * n_channels));
     chunk_max = std::max<int64_t>(hpw, std::min<int64_t>(chunk_max / hpw * hpw, 32768));
     int rc = e->d_tail.reserve((size_t)e->cfg.channels * H * sizeof(float));
     if (rc) return rc;
@@ -571,7 +614,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     auto run_chunk = [&](int64_t k0, int64_t kc, bool tail_only) -> int {
         int rcc;
         const size_t spec_floats = (size_t)n_channels * kc * N * 2;
-        if ((!big || e->cfg.kernel) && (rcc = e->d_spec.reserve(spec_floats * sizeof(float)))) return rcc;
+        if (!big && (rcc = e->d_spec.reserve(spec_floats * sizeof(float)))) return rcc;
         if ((rcc = e->d_ybuf.reserve((size_t)n_channels * kc * N * sizeof(float)))) return rcc;
         rc::HopParams q = p;
         q.spec = (float2 *)e->d_spec.p;
@@ -593,7 +636,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
 #ifndef RC_BIGCR
 #define RC_BIGCR 1
 #endif
-        if (RC_BIGCR && big && !e->cfg.kernel && e->cfg.pitch_multiple >= 1) {
+        if (RC_BIGCR && big && e->cfg.pitch_multiple >= 1) {
             // stage C with the overlap-add fused: runs of hops per quarter, tail in registers; the
             // tail of the chunk's last hop goes to a staging buffer and replaces d_tail afterwards
             // (the first run of this very launch still reads the old one)
@@ -621,45 +664,13 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
                                   (size_t)n_channels * H * sizeof(float), hipMemcpyDeviceToDevice, s));
             launches += 3;
             return RC_OK;
-        } else if (big && !e->cfg.kernel) {
+        } else if (big) {
             for (int stage = 0; stage < 3; ++stage) RC_HIP(rc::launch_big(stage, b, s));
             launches += 3;
-        } else {
-            if (big) {
-                RC_HIP(rc::launch_big(0, b, s));
-                RC_HIP(rc::launch_big(1, b, s, rc::MODE_FORWARD));
-            } else {
-                RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, q, s));
-            }
-            if (e->cfg.kernel) {
-                e->h_spec.resize(spec_floats);
-                e->h_spec2.resize((size_t)N * 2);
-                RC_HIP(hipMemcpyAsync(e->h_spec.data(), e->d_spec.p, spec_floats * sizeof(float),
-                                      hipMemcpyDeviceToHost, s));
-                RC_HIP(hipStreamSynchronize(s));
-                for (int64_t w0 = 0; w0 < kc; w0 += hpw) {
-                    for (uint32_t c = 0; c < n_channels; ++c) {
-                        for (int64_t h = w0; h < std::min<int64_t>(w0 + hpw, kc); ++h) {
-                            float *sp = e->h_spec.data() + ((size_t)c * kc + h) * N * 2;
-                            // src/fft.rs:86-99: copy in, call apply(now_ms, bins), copy out
-                            const int krc = e->cfg.kernel(now_ms(e), sp, e->h_spec2.data(), N,
-                                                          e->cfg.kernel_user);
-                            if (krc == 0) memcpy(sp, e->h_spec2.data(), (size_t)N * 2 * sizeof(float));
-                            // non-zero == panic: keep the unmodified spectrum (src/fft.rs:100-106)
-                        }
-                    }
-                }
-                RC_HIP(hipMemcpyAsync(e->d_spec.p, e->h_spec.data(), spec_floats * sizeof(float),
-                                      hipMemcpyHostToDevice, s));
-            }
-            if (big) {
-                RC_HIP(rc::launch_big(1, b, s, rc::MODE_RESYNTH));
-                RC_HIP(rc::launch_big(2, b, s));
-                launches += 4;
-            } else {
-                RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, q, s));
-                launches += 2;
-            }
+        } else {  // negative pitch multiples, N <= 16384: spectrum -> y_k through scratch
+            RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, q, s));
+            RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, q, s));
+            launches += 2;
         }
         rc::OlaParams o{};
         o.ybuf = (const float *)e->d_ybuf.p;
@@ -678,10 +689,9 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         o.log2n = (uint32_t)e->log2n;
         RC_HIP(rc::launch_ola(o, s, tail_only));
         launches += 2;
-        if (e->cfg.kernel) RC_HIP(hipStreamSynchronize(s));  // h_spec is reused by the next chunk
         return RC_OK;
     };
-    if (timed) RC_HIP(hipEventRecord(e->ev0, s));
+    if (timed) RC_HIP(hipEventRecord(e->ev0[e->timed_calls % rc_engine::kRing], s));
     if (hop_first == 0)  // a fresh stream starts from H zeros (src/stretcher.rs:58-59)
         RC_HIP(hipMemsetAsync((float *)e->d_tail.p + (size_t)ch_first * H, 0,
                               (size_t)n_channels * H * sizeof(float), s));
@@ -697,8 +707,8 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         if ((rc = run_chunk(k0, kc, false))) return rc;
     }
     if (timed) {
-        RC_HIP(hipEventRecord(e->ev1, s));
-        e->stats_valid = true;
+        RC_HIP(hipEventRecord(e->ev1[e->timed_calls % rc_engine::kRing], s));
+        e->timed_calls++;
         e->stats_hops = (uint64_t)hop_count * n_channels;
         e->stats_launches = launches;
     }
@@ -755,6 +765,7 @@ extern "C" {
 
 const char *rc_last_error(void) { return g_err.c_str(); }
 int rc_abi_version(void) { return RC_ABI_VERSION; }
+const char *rc_kernel_id(void) { return RC_KERNEL_ID; }
 
 int rc_device_count(void) {
     int n = 0;
@@ -828,6 +839,7 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->seed_mixed = mix64(cfg->seed);
     e->ch.resize(cfg->channels);
+    e->kernel_next_hop.assign(cfg->channels, 0);
     const uint32_t N = cfg->window_len, M = N / 2, H = N / 2;
     std::vector<float> w(N), env(H);
     if (cfg->window) memcpy(w.data(), cfg->window, N * sizeof(float));
@@ -887,8 +899,15 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
             return cleanup(fail(RC_EHIP, "%s failed: %s", #expr, hipGetErrorString(_e)));       \
     } while (0)
     RC_HIP_C(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    RC_HIP_C(hipEventCreate(&e->ev0));
-    RC_HIP_C(hipEventCreate(&e->ev1));
+    for (int i = 0; i < rc_engine::kRing; ++i) {
+        RC_HIP_C(hipEventCreate(&e->ev0[i]));
+        RC_HIP_C(hipEventCreate(&e->ev1[i]));
+    }
+    RC_HIP_C(hipEventCreateWithFlags(&e->ev_last, hipEventDisableTiming));
+    RC_HIP_C(hipHostMalloc((void **)&e->h_err, sizeof(uint32_t), hipHostMallocMapped));
+    *e->h_err = 0;
+    RC_HIP_C(hipHostGetDevicePointer((void **)&e->d_err, e->h_err, 0));
+    if (const char *diag = getenv("ROCODER_DIAG")) e->diag_flags = (uint32_t)strtoul(diag, nullptr, 0);
     RC_HIP_C(hipMalloc((void **)&e->d_window, N * sizeof(float)));
     RC_HIP_C(hipMalloc((void **)&e->d_env, H * sizeof(float)));
     RC_HIP_C(hipMalloc((void **)&e->d_wtab, wtab.size() * sizeof(float2)));
@@ -948,9 +967,13 @@ void rc_engine_destroy(rc_engine *e) {
     if (e->kp.ev_done) (void)hipEventDestroy(e->kp.ev_done);
     if (e->kp.kf) (void)hipStreamDestroy(e->kp.kf);
     if (e->kp.kb) (void)hipStreamDestroy(e->kp.kb);
-    if (e->ev0) (void)hipEventDestroy(e->ev0);
-    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    for (int i = 0; i < rc_engine::kRing; ++i) {
+        if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]);
+        if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]);
+    }
+    if (e->ev_last) (void)hipEventDestroy(e->ev_last);
     if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->h_err) (void)hipHostFree(e->h_err);
     delete e;
 }
 
@@ -992,7 +1015,7 @@ int rc_engine_is_done(const rc_engine *e, uint32_t channel) {
 
 int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out_cap, size_t *n_out) try {
     if (!e || channel >= e->ch.size() || !out) return fail(RC_EINVAL, "bad argument");
-    int rc = check_gpu_path(e);
+    int rc = check_device_error(e);
     if (rc) return rc;
     Channel &c = e->ch[channel];
     const rc_params &P = e->par;
@@ -1046,6 +1069,7 @@ int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out
         RC_HIP(hipMemcpyAsync(e->h_io.data(), e->d_out.p, (size_t)nwin * wout * sizeof(float),
                               hipMemcpyDeviceToHost, e->stream));
         RC_HIP(hipStreamSynchronize(e->stream));
+        if ((rc = check_device_error(e))) return rc;
         for (uint64_t w = 0; w < nwin; ++w)
             c.ready.emplace_back(e->h_io.begin() + w * wout, e->h_io.begin() + (w + 1) * wout);
         c.next_window += nwin;
@@ -1072,15 +1096,13 @@ int rc_engine_stretch_device_range(rc_engine *e, const float *d_in, size_t in_st
                                    uint64_t win_count, float *d_out, size_t out_stride,
                                    size_t out_cap, void *hip_stream) try {
     if (!e || !d_out || (!d_in && in_len)) return fail(RC_EINVAL, "null argument");
-    int rc = check_gpu_path(e);
+    int rc = check_device_error(e);
     if (rc) return rc;
     if (ch_first + ch_count > e->cfg.channels) return fail(RC_EINVAL, "channel range out of bounds");
     const uint64_t total_win = offline_windows(e->par, in_len);
     if (win_first + win_count > total_win) return fail(RC_EINVAL, "window range out of bounds");
     const uint64_t wout = e->par.window_out_len;
     if (out_cap < win_count * wout) return fail(RC_ECAPACITY, "out_cap %zu < %llu", out_cap, (unsigned long long)(win_count * wout));
-    if (e->cfg.kernel && win_first != 0 && !e->tail_zeroed)
-        return fail(RC_EINVAL, "a user kernel carries the overlap tail: ranges must be issued in order from window 0");
     RC_HIP(hipSetDevice(e->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
     const uint32_t hpw = e->par.hops_per_window;
@@ -1107,7 +1129,7 @@ int rc_engine_stretch_device(rc_engine *e, const float *d_in, size_t in_stride, 
 int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, float *const *out,
                            size_t out_cap, size_t *out_len) try {
     if (!e || !in || !out) return fail(RC_EINVAL, "null argument");
-    int rc = check_gpu_path(e);
+    int rc = check_device_error(e);
     if (rc) return rc;
     const uint32_t C = e->cfg.channels;
     const uint64_t total_win = offline_windows(e->par, in_len);
@@ -1128,6 +1150,7 @@ int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, 
         RC_HIP(hipMemcpyAsync(out[c], (float *)e->d_out.p + (size_t)c * n_out, n_out * sizeof(float),
                               hipMemcpyDeviceToHost, e->stream));
     RC_HIP(hipStreamSynchronize(e->stream));
+    if ((rc = check_device_error(e))) return rc;
     if (out_len) *out_len = n_out;
     return RC_OK;
 } catch (...) {
@@ -1138,15 +1161,28 @@ int rc_engine_synchronize(rc_engine *e) {
     if (!e) return fail(RC_EINVAL, "null engine");
     RC_HIP(hipSetDevice(e->device));
     RC_HIP(hipStreamSynchronize(e->stream));
+    return check_device_error(e);
+}
+
+int rc_engine_kernel_times(rc_engine *e, float *ms, size_t cap, size_t *n_out) {
+    if (!e || (!ms && cap)) return fail(RC_EINVAL, "null argument");
+    const uint64_t have = std::min<uint64_t>(e->timed_calls, rc_engine::kRing);
+    const size_t n = (size_t)std::min<uint64_t>(have, cap);
+    if (n) RC_HIP(hipEventSynchronize(e->ev1[(e->timed_calls - 1) % rc_engine::kRing]));
+    if (int rc = check_device_error(e)) return rc;
+    for (size_t i = 0; i < n; ++i) {  // oldest of the last n first
+        const uint64_t call = e->timed_calls - n + i;
+        RC_HIP(hipEventElapsedTime(&ms[i], e->ev0[call % rc_engine::kRing], e->ev1[call % rc_engine::kRing]));
+    }
+    if (n_out) *n_out = n;
     return RC_OK;
 }
 
 int rc_engine_last_kernel_stats(rc_engine *e, float *kernel_ms, uint64_t *hops, uint32_t *launches) {
     if (!e) return fail(RC_EINVAL, "null engine");
-    if (!e->stats_valid) return fail(RC_EINVAL, "no timed launch recorded yet");
-    RC_HIP(hipEventSynchronize(e->ev1));
+    if (!e->timed_calls) return fail(RC_EINVAL, "no timed launch recorded yet");
     float ms = 0.f;
-    RC_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+    if (int rc = rc_engine_kernel_times(e, &ms, 1, nullptr)) return rc;
     if (kernel_ms) *kernel_ms = ms;
     if (hops) *hops = e->stats_hops;
     if (launches) *launches = e->stats_launches;

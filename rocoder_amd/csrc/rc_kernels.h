@@ -48,6 +48,12 @@ struct HopParams {
     uint32_t *seam_flag;
     uint32_t *run_counter;
     uint32_t seam_epoch;
+    // A run that never sees its successor's flag within seam_spin_limit polls gives up, leaves its seam
+    // samples unwritten and reports through *err_word (host-visible pinned memory; RC_ERR_SEAM_TIMEOUT):
+    // the engine turns that into RC_EHIP. diag_flags is test-only (RC_DIAG_*).
+    uint32_t seam_spin_limit;
+    uint32_t diag_flags;
+    uint32_t *err_word;
     // spectrum modes (user-kernel path)
     float2 *spec;          // [n_channels][hop_count][N] natural-order spectrum
     float *ybuf;           // [n_channels][hop_count][N] windowed resynthesis output y_k
@@ -114,7 +120,14 @@ struct BigOlaParams {
     uint32_t tail_only;     // 1: compute tails only, store nothing to out
 };
 
+// kernel generation (rc_kernel_id): bump whenever a change to the kernels can move a measurement
+#define RC_KERNEL_ID "hop3/r02a"
+
 enum HopMode { MODE_FUSED = 0, MODE_FORWARD = 1, MODE_RESYNTH = 2 };
+// values a kernel may leave in *HopParams::err_word
+constexpr uint32_t RC_ERR_SEAM_TIMEOUT = 1;
+// HopParams::diag_flags (ROCODER_DIAG, tests only): the producer of a seam never publishes its flag
+constexpr uint32_t RC_DIAG_SKIP_SEAM_PUBLISH = 1;
 
 // Geometry chosen by the kernels for a window length (threads per workgroup, LDS bytes).
 bool hop_geometry(int log2n, int *threads, size_t *lds_bytes);

@@ -1759,9 +1759,12 @@ __global__ __launch_bounds__(256, 3) void hop3_kernel(const HopParams p) {
                 for (int q = 0; q < PH; ++q)
                     __hip_atomic_store(hs + T * q, __builtin_bit_cast(unsigned long long, y[q]),
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have landed
+                // every storing wave drains its own write-through stores before the barrier; only then
+                // may lane 0 publish (a workgroup-scope fence emits no vmcnt wait on gfx950, and inline
+                // asm is the form the compiler cannot drop: MI355X_MICROARCH.md, valid hand-off forms)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid == 0)
+                if (tid == 0 && !(p.diag_flags & RC_DIAG_SKIP_SEAM_PUBLISH))
                     __hip_atomic_store(p.seam_flag + gr, p.seam_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 store_head(k, y);
@@ -1772,16 +1775,25 @@ __global__ __launch_bounds__(256, 3) void hop3_kernel(const HopParams p) {
     }
     if (has_next) {
         // hop k_end is the first hop of run gr + 1: its workgroup started after this one and stashed
-        // the head one hop after its start. Bounded wait (never reached unless the launch is broken).
+        // the head one hop after its start. Bounded wait (never reached unless the launch is broken):
+        // on expiry the seam samples stay unwritten and the host is told through *err_word.
+        unsigned *okw = reinterpret_cast<unsigned *>(lds + SCR);
         if (tid == 0) {
-            for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+            unsigned ok = 0;
+            for (unsigned spin = 0; spin < p.seam_spin_limit; ++spin) {
                 if (__hip_atomic_load(p.seam_flag + gr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                    p.seam_epoch)
+                    p.seam_epoch) {
+                    ok = 1;
                     break;
+                }
                 __builtin_amdgcn_s_sleep(32);
             }
+            if (!ok && p.err_word)
+                __hip_atomic_store(p.err_word, RC_ERR_SEAM_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            *okw = ok;
         }
         __syncthreads();
+        if (*reinterpret_cast<volatile unsigned *>(okw) == 0) return;
         const unsigned long long *hs = (const unsigned long long *)(p.seam_head + (size_t)(gr + 1) * H) + tid;
         v2f head[PH];
 #pragma unroll

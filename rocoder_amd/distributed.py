@@ -53,61 +53,95 @@ def shard_plan(channels: int, total_windows: int, world_size: int) -> List[Shard
     return shards
 
 
-def stretch_sharded(compute: Callable[[Shard], "object"], channels: int, total_windows: int,
-                    window_out_len: int, group=None, dst: Optional[int] = 0):
-    """Run this rank's shards with `compute(shard) -> tensor[ch_count, win_count*window_out_len]`
-    and concatenate: returns the full [channels, total_windows*window_out_len] tensor on rank
-    `dst` (every rank when dst is None), else None. One all_gather of equally padded segments."""
+def shard_view(full, s: Shard, window_out_len: int):
+    """The block of the final [channels, windows * window_out_len] layout a shard fills. A shard is
+    either part of ONE channel or a block of WHOLE channels (shard_plan), so in a contiguous `full`
+    the block is one contiguous span of memory: collectives can land in it directly."""
+    return full[s.ch_first:s.ch_first + s.ch_count,
+                s.win_first * window_out_len:(s.win_first + s.win_count) * window_out_len]
+
+
+def stretch_sharded(compute: Callable[..., "object"], channels: int, total_windows: int,
+                    window_out_len: int, group=None, dst: Optional[int] = 0, full=None):
+    """Run this rank's shards with `compute(shard, out=None) -> tensor[ch_count, win_count*window_out_len]`
+    and concatenate: returns the full [channels, total_windows*window_out_len] tensor on rank `dst`
+    (every rank when dst is None), else None.
+
+    The concat is the path's only collective (north_star: RCCL for the multi-channel concat only) and
+    moves every output byte exactly once, straight into its final place: a rank that holds `full`
+    computes its own shards INTO their views of it; every other shard travels as one message into its
+    view (grouped send / recv to the root, or one broadcast per shard when every rank wants the
+    result). No padding to the longest segment, no staging list, no block-by-block re-copy.
+    `full` may be passed in (reused across calls); it must be contiguous."""
     import torch
     import torch.distributed as dist
 
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     plan = shard_plan(channels, total_windows, world)
-    mine = [s for s in plan if s.rank == rank]
-    outs = [compute(s) for s in mine]
-    per_rank = {}
+    holds_full = dst is None or rank == dst
+    width = total_windows * window_out_len
+    outs = {}
+    device = None
+    if holds_full and full is not None:
+        device = full.device
     for s in plan:
-        per_rank[s.rank] = per_rank.get(s.rank, 0) + s.ch_count * s.win_count * window_out_len
-    seg = max(per_rank.values()) if per_rank else 0
-    ref = outs[0] if outs else None
-    device = ref.device if ref is not None else torch.device("cpu")
-    if ref is None and dist.get_backend(group) == "nccl":
-        device = torch.device("cuda", torch.cuda.current_device())
-    buf = torch.zeros(seg, dtype=torch.float32, device=device)
-    off = 0
-    for o in outs:
-        flat = o.reshape(-1)
-        buf[off:off + flat.numel()] = flat
-        off += flat.numel()
+        if s.rank != rank:
+            continue
+        if holds_full and full is not None:
+            outs[s] = compute(s, out=shard_view(full, s, window_out_len))
+        else:
+            outs[s] = compute(s)
+            device = outs[s].device
+    if device is None:
+        device = (torch.device("cuda", torch.cuda.current_device())
+                  if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+    if holds_full and full is None:
+        full = torch.empty((channels, width), dtype=torch.float32, device=device)
+        for s, o in outs.items():  # first call without a caller buffer: one placement copy
+            shard_view(full, s, window_out_len).copy_(o)
+    if holds_full:
+        assert full.is_contiguous() and tuple(full.shape) == (channels, width)
     if dst is None:
-        gathered = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(gathered, buf, group=group)
-    else:
-        gathered = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-        dist.gather(buf, gathered, dst=dst, group=group)
-        if rank != dst:
-            return None
-    full = torch.empty((channels, total_windows * window_out_len), dtype=torch.float32, device=device)
-    offs = {r: 0 for r in range(world)}
+        for s in plan:  # every rank receives every foreign shard into its final place
+            v = shard_view(full, s, window_out_len)
+            assert v.is_contiguous() or s.ch_count == 1 or s.win_count == total_windows
+            dist.broadcast(v, src=dist.get_global_rank(group, s.rank) if group is not None else s.rank,
+                           group=group)
+        return full
+    ops = []
     for s in plan:
-        n = s.ch_count * s.win_count * window_out_len
-        blk = gathered[s.rank][offs[s.rank]:offs[s.rank] + n].reshape(s.ch_count, -1)
-        offs[s.rank] += n
-        full[s.ch_first:s.ch_first + s.ch_count,
-             s.win_first * window_out_len:(s.win_first + s.win_count) * window_out_len] = blk
-    return full
+        if s.rank == dst:
+            continue
+        peer_dst = dist.get_global_rank(group, dst) if group is not None else dst
+        peer_src = dist.get_global_rank(group, s.rank) if group is not None else s.rank
+        if rank == dst:
+            ops.append(dist.P2POp(dist.irecv, shard_view(full, s, window_out_len), peer_src, group))
+        elif rank == s.rank:
+            o = outs[s]
+            ops.append(dist.P2POp(dist.isend, o if o.is_contiguous() else o.contiguous(), peer_dst, group))
+    if ops:
+        if dist.get_backend(group) == "nccl":
+            for w in dist.batch_isend_irecv(ops):  # one grouped RCCL launch
+                w.wait()
+        else:
+            for w in [op.op(op.tensor, op.peer, group=op.group) for op in ops]:
+                w.wait()
+    return full if rank == dst else None
 
 
 def engine_compute(engine, x):
     """compute() for `stretch_sharded` backed by the HIP engine on this rank's GPU.
-    x: torch float32 CUDA tensor [channels, L] (replicated input; it is small)."""
+    x: torch float32 CUDA tensor [channels, L] (replicated input; it is small). With `out` (a view
+    of the final layout, any row stride) the engine writes the shard straight into it."""
     import torch
 
     wout = engine.params.window_out_len
 
-    def compute(s: Shard):
-        out = torch.empty((s.ch_count, s.win_count * wout), dtype=torch.float32, device=x.device)
+    def compute(s: Shard, out=None):
+        if out is None:
+            out = torch.empty((s.ch_count, s.win_count * wout), dtype=torch.float32, device=x.device)
+        assert out.stride(1) == 1 and tuple(out.shape) == (s.ch_count, s.win_count * wout)
         stream = torch.cuda.current_stream(x.device).cuda_stream
         if stream == 0:  # see Engine.stretch_tensor
             torch.cuda.current_stream(x.device).synchronize()

@@ -221,6 +221,13 @@ class Engine:
                                                   C.byref(launches)))
         return float(ms.value), int(hops.value), int(launches.value)
 
+    def kernel_times(self, n: int = 64) -> List[float]:
+        """Event times (ms) of the kernel launches of the last min(n, 64) offline calls, oldest first."""
+        buf = (C.c_float * n)()
+        got = C.c_size_t(0)
+        check(self._L.rc_engine_kernel_times(self._h, buf, n, C.byref(got)))
+        return [float(buf[i]) for i in range(got.value)]
+
     # ---- single hop (ReFFT seam)
     def forward_fft(self, samples) -> np.ndarray:
         s = np.ascontiguousarray(samples, dtype=np.float32)

@@ -51,13 +51,24 @@ def _worker(rank, world, port, x, full_ref, N, f, p, wout, nwin, dst, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        def compute(s: Shard):
+        def compute(s: Shard, out=None):
             # checker-side compute: the shard's slice of the oracle's full output
-            blk = full_ref[s.ch_first:s.ch_first + s.ch_count,
-                           s.win_first * wout:(s.win_first + s.win_count) * wout]
-            return torch.from_numpy(np.ascontiguousarray(blk))
+            blk = torch.from_numpy(np.ascontiguousarray(
+                full_ref[s.ch_first:s.ch_first + s.ch_count,
+                         s.win_first * wout:(s.win_first + s.win_count) * wout]))
+            if out is not None:
+                out.copy_(blk)
+                return out
+            return blk
 
+        # twice: without a caller buffer, then into a reused one (the bench's form)
         out = stretch_sharded(compute, x.shape[0], nwin, wout, dst=dst)
+        if dst is None or rank == dst:
+            buf = torch.full_like(out, float("nan"))
+            out2 = stretch_sharded(compute, x.shape[0], nwin, wout, dst=dst, full=buf)
+            assert out2 is buf and torch.equal(out2, out)
+        else:
+            assert stretch_sharded(compute, x.shape[0], nwin, wout, dst=dst) is None
         if dst is None or rank == dst:
             q.put((rank, np.array_equal(out.numpy(), full_ref)))
         else:
@@ -67,7 +78,7 @@ def _worker(rank, world, port, x, full_ref, N, f, p, wout, nwin, dst, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dst", [(2, 0), (3, None)])
+@pytest.mark.parametrize("world,dst", [(2, 0), (3, None), (3, 1)])
 def test_sharded_gather_gloo(world, dst):
     import torch.multiprocessing as mp
 

@@ -583,6 +583,112 @@ def test_baseline_c5_full_size():
             del seg
 
 
+GAIN2_C = r"""
+#include <stddef.h>
+#include <stdint.h>
+/* README.md:121-128's example kernel in its C-ABI form (include/rocoder_hip.h rc_freq_kernel) */
+int apply(uint64_t time_ms, const float *in, float *out, size_t n, void *user) {
+    (void)time_ms; (void)user;
+    for (size_t i = 0; i < 2 * n; ++i) out[i] = in[i] * 2.0f;
+    return 0;
+}
+"""
+
+
+def _compiled_gain2(tmp_path):
+    import subprocess
+
+    from rocoder_amd.stretcher import load_kernel_library
+
+    src, so = tmp_path / "gain2.c", tmp_path / "libgain2.so"
+    src.write_text(GAIN2_C)
+    subprocess.run(["gcc", "-O2", "-shared", "-fPIC", "-o", str(so), str(src)], check=True)
+    return load_kernel_library(str(so))
+
+
+def test_baseline_c4_window_16384_user_kernel(tmp_path):
+    """BASELINE C4 at its own window length: stereo, window 16384, factor 8, the README's x2.0 apply()
+    (src/fft.rs:76-108, README.md:121-128) as a compiled C-ABI kernel. Runs hop_kernel<14, FORWARD /
+    RESYNTH> + ola_kernel; F_C4 == 2 F_C2 cross-checks them against the fused hop kernel of C2."""
+    import torch
+
+    ra = _engine_mod()
+    k = _compiled_gain2(tmp_path)
+    N, f, seed = 16384, 8.0, 0x5EED
+    # (a) against the oracle, every sample, at an oracle-affordable length
+    L = 400_000
+    x = np.stack([onp.synth_input(c, L) for c in range(2)])
+    got = ra.stretch(x, window_len=N, factor=f, seed=seed, kernel=k, kernel_time_ms=77)
+    ref = oc.stretch_offline(x, N, f, 1.0, 1, seed=seed, kernel=_kernel_for(2.0))
+    for c in range(2):
+        assert_parity(got[c], ref[c], f"C4 ch{c}")
+    # (b) linearity at the size tools/bench_configs.py times C4 on: F_C4 == 2 F_C2
+    L = 2_646_000
+    x = np.stack([onp.synth_input(c, L) for c in range(2)])
+    xt = torch.from_numpy(x).cuda()
+    with ra.Engine(window_len=N, factor=f, channels=2, seed=seed) as e2:
+        f2 = e2.stretch_tensor(xt).clone()
+        torch.cuda.synchronize()
+    with ra.Engine(window_len=N, factor=f, channels=2, seed=seed, kernel=k, kernel_time_ms=77) as e4:
+        f4 = e4.stretch_tensor(xt)
+        torch.cuda.synchronize()
+        _, hops, _ = e4.last_kernel_stats()
+    assert hops == 2 * (f4.shape[1] // (N // 2))
+    d = (f4.double() - 2.0 * f2.double())
+    rel = float(d.pow(2).mean().sqrt() / f2.double().pow(2).mean().sqrt())
+    assert rel <= 2e-6, rel
+
+
+@pytest.mark.parametrize("p", [1, 3])
+def test_16384_full_length_every_sample_vs_oracle(p):
+    """Every output sample of a mid-size job (L = 3.2 M per channel: ~800 runs of 8 hops, all seam, epoch
+    and run-planner positions) against the oracle, not a prefix or sampled hops."""
+    import torch
+
+    ra = _engine_mod()
+    N, f, L, seed = 16384, 8.0, 3_200_000, 0xF00D
+    x = np.stack([onp.synth_input(c, L) for c in range(2)])
+    with ra.Engine(window_len=N, factor=f, pitch_multiple=p, channels=2, seed=seed) as e:
+        got = e.stretch_tensor(torch.from_numpy(x).cuda()).cpu().numpy()
+    ref = oc.stretch_offline(x, N, f, 1.0, p, seed=seed)
+    assert got.shape == ref.shape
+    for c in range(2):
+        assert_parity(got[c], ref[c], f"full length p={p} ch{c}")
+    # no isolated bad stretch hides inside a good global RMS: per-half-window blocks too
+    H = N // 2 // p if (N // 2) % p == 0 else N // 2
+    nb = got.shape[1] // H
+    d = (got[:, :nb * H].astype(np.float64) - ref[:, :nb * H]).reshape(2, nb, H)
+    blk = np.sqrt((d * d).mean(axis=2))
+    assert blk.max() <= 3e-4, (float(blk.max()), np.unravel_index(blk.argmax(), blk.shape))
+
+
+def test_seam_wait_expiry_fails_loudly(monkeypatch):
+    """The run-seam hand-over of the N = 16384 kernel has a bounded wait. With the diagnostic flag that
+    makes producers skip the publish (ROCODER_DIAG=1), consumers must give up, leave a device error
+    word and the engine must return RC_EHIP - never silently consume a stale stash."""
+    import torch
+
+    ra = _engine_mod()
+    from rocoder_amd import _lib
+
+    x = np.stack([onp.synth_input(c, 1_200_000) for c in range(2)])
+    xt = torch.from_numpy(x).cuda()
+    monkeypatch.setenv("ROCODER_DIAG", "1")
+    with ra.Engine(window_len=16384, factor=8.0, channels=2, seed=3) as e:
+        e.stretch_tensor(xt)
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.RocoderError) as ei:
+            e.synchronize()
+        assert ei.value.code == _lib.RC_EHIP and "seam" in str(ei.value)
+        e.synchronize()  # reported once
+    monkeypatch.delenv("ROCODER_DIAG")
+    with ra.Engine(window_len=16384, factor=8.0, channels=2, seed=3) as e:
+        out = e.stretch_tensor(xt)
+        torch.cuda.synchronize()
+        e.synchronize()
+        assert torch.isfinite(out).all()
+
+
 def test_unsupported_configs_fail_loudly():
     ra = _engine_mod()
     from rocoder_amd import _lib
