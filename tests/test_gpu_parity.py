@@ -675,9 +675,9 @@ def test_seam_wait_expiry_fails_loudly(monkeypatch):
     xt = torch.from_numpy(x).cuda()
     monkeypatch.setenv("ROCODER_DIAG", "1")
     with ra.Engine(window_len=16384, factor=8.0, channels=2, seed=3) as e:
-        e.stretch_tensor(xt)
-        torch.cuda.synchronize()
         with pytest.raises(_lib.RocoderError) as ei:
+            e.stretch_tensor(xt)  # (asynchronous on a caller stream: the error then comes from the next call)
+            torch.cuda.synchronize()
             e.synchronize()
         assert ei.value.code == _lib.RC_EHIP and "seam" in str(ei.value)
         e.synchronize()  # reported once
