@@ -121,13 +121,16 @@ struct BigOlaParams {
 };
 
 // kernel generation (rc_kernel_id): bump whenever a change to the kernels can move a measurement
-#define RC_KERNEL_ID "hop3/r02a"
+#define RC_KERNEL_ID "hop4/r02b"
 
 enum HopMode { MODE_FUSED = 0, MODE_FORWARD = 1, MODE_RESYNTH = 2 };
 // values a kernel may leave in *HopParams::err_word
 constexpr uint32_t RC_ERR_SEAM_TIMEOUT = 1;
 // HopParams::diag_flags (ROCODER_DIAG, tests only): the producer of a seam never publishes its flag
 constexpr uint32_t RC_DIAG_SKIP_SEAM_PUBLISH = 1;
+// run the previous kernel generation of the N = 16384 path (hop3) instead of hop4: A/B timing and the
+// bit-exactness test between the two
+constexpr uint32_t RC_DIAG_PREV_KERNEL = 2;
 
 // Geometry chosen by the kernels for a window length (threads per workgroup, LDS bytes).
 bool hop_geometry(int log2n, int *threads, size_t *lds_bytes);

@@ -1032,9 +1032,12 @@ __device__ __forceinline__ void phase_cs2_x(uint32_t x, v2f &lo, v2f &up) {
     lo = v2f{a, b};
     up = v2f{c, d};
 }
-template <int LOG2N>
+__device__ __forceinline__ v2f vsel(bool c, v2f a, v2f b) { return v2f{c ? a.x : b.x, c ? a.y : b.y}; }
+// dc (lane predicate): this lane's pair is bin 0 with itself - N - 0 is bin 0 again and M - 0 is bin M, so the
+// phases of "N - ja" and "M - ja" are those of bins ja and M + ja (only ever true for one lane of one slot)
+template <int LOG2N, bool DC = false>
 __device__ __forceinline__ void pair_regs_pk(v2f A, v2f Bp, v2f w, uint32_t x1, PhaseKey key, v2f &VA,
-                                             v2f &VB) {
+                                             v2f &VB, bool dc = false) {
     constexpr uint32_t N = 1u << LOG2N, M = N / 2;
     const uint32_t cM = M * key.mul + 2u * key.k0;
     const float nkappa = -0.25f / (float)N;
@@ -1050,6 +1053,10 @@ __device__ __forceinline__ void pair_regs_pk(v2f A, v2f Bp, v2f w, uint32_t x1, 
     v2f cs1, cs2, cs3, cs4;
     phase_cs2_x(x1, cs1, cs4);       // bins ja and M + ja
     phase_cs2_x(cM - x1, cs3, cs2);  // bins M - ja and N - ja
+    if (DC) {
+        cs2 = vsel(dc, cs1, cs2);
+        cs3 = vsel(dc, cs4, cs3);
+    }
     const v2f P0 = cs1 + cs2 * cj;   // (c1 + c2, s1 - s2)
     const v2f Q0 = cs4 + cs3 * cj;   // (c4 + c3, s4 - s3)
     const v2f m1 = __builtin_shufflevector(mm, mm, 0, 0), m2 = __builtin_shufflevector(mm, mm, 1, 1);
@@ -1060,6 +1067,53 @@ __device__ __forceinline__ void pair_regs_pk(v2f A, v2f Bp, v2f w, uint32_t x1, 
     const v2f t0 = R * __builtin_shufflevector(w, w, 0, 0);
     const v2f Uc = __builtin_elementwise_fma(__builtin_shufflevector(R, R, 1, 0),
                                              __builtin_shufflevector(w, w, 1, 1) * cj, t0);
+    const v2f Us = __builtin_shufflevector(Uc, Uc, 1, 0);      // (uy, ux)
+    VA = S + Us * jc;                                          // (sx - uy, sy + ux)
+    VB = Us + S * cj;                                          // (sx + uy, ux - sy)
+}
+
+// hop4's variant of the pair: the same algebra with (a) the 1/(4N) scale left out (hop4 folds it into the
+// synthesis window constants - an exact power of two), (b) the two complex products written with VOP3P
+// source modifiers instead of materialised (-w.y, w.x) / (w.y, -w.y) operands.
+//   cmul_fma(a, w, t)   = t + a.yy * (-w.y, w.x)      -> with t = a.xx * w this is a * w
+//   cmulc_fma(a, w, t)  = t + a.yx * (w.y, -w.y)      -> with t = a * w.xx this is a * conj(w)
+__device__ __forceinline__ v2f cmul_fma(v2f a, v2f w, v2f t) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ v2f cmulc_fma(v2f a, v2f w, v2f t) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+template <int LOG2N, bool DC = false>
+__device__ __forceinline__ void pair_regs_pk4(v2f A, v2f Bp, v2f w, uint32_t x1, PhaseKey key, v2f &VA,
+                                              v2f &VB, bool dc = false) {
+    constexpr uint32_t N = 1u << LOG2N, M = N / 2;
+    const uint32_t cM = M * key.mul + 2u * key.k0;
+    const v2f cj = {1.0f, -1.0f}, jc = {-1.0f, 1.0f};
+    const v2f Bc = Bp * cj;                                    // conj(Bp) (fused into E, D by the compiler)
+    const v2f E = A + Bc, D = A - Bc;                          // 2E, 2D
+    const v2f T = cmul_fma(D, w, __builtin_shufflevector(D, D, 0, 0) * w);  // T = w D
+    const v2f U = __builtin_shufflevector(E, E, 0, 0) + __builtin_shufflevector(T, T, 1, 1) * cj;
+    const v2f V = __builtin_shufflevector(E, E, 1, 1) + __builtin_shufflevector(T, T, 0, 0) * jc;
+    const v2f q2 = __builtin_elementwise_fma(V, V, U * U);     // (|X1|^2, |X2c|^2)
+    const v2f mm = v2f{__builtin_amdgcn_sqrtf(q2.x), __builtin_amdgcn_sqrtf(q2.y)};
+    v2f cs1, cs2, cs3, cs4;
+    phase_cs2_x(x1, cs1, cs4);       // bins ja and M + ja
+    phase_cs2_x(cM - x1, cs3, cs2);  // bins M - ja and N - ja
+    if (DC) {
+        cs2 = vsel(dc, cs1, cs2);
+        cs3 = vsel(dc, cs4, cs3);
+    }
+    const v2f P0 = cs1 + cs2 * cj;   // (c1 + c2, s1 - s2)
+    const v2f Q0 = cs4 + cs3 * cj;   // (c4 + c3, s4 - s3)
+    const v2f m1 = __builtin_shufflevector(mm, mm, 0, 0), m2 = __builtin_shufflevector(mm, mm, 1, 1);
+    const v2f Pz = P0 * m1;
+    const v2f S = __builtin_elementwise_fma(Q0, m2, Pz);
+    const v2f R = __builtin_elementwise_fma(Q0, -m2, Pz);
+    const v2f Uc = cmulc_fma(R, w, R * __builtin_shufflevector(w, w, 0, 0));  // conj(w) R
     const v2f Us = __builtin_shufflevector(Uc, Uc, 1, 0);      // (uy, ux)
     VA = S + Us * jc;                                          // (sx - uy, sy + ux)
     VB = Us + S * cj;                                          // (sx + uy, ux - sy)
@@ -1108,6 +1162,10 @@ constexpr double cx_sqrt(double x) {
 constexpr double HANN_ENV_AMP = 1.0 - (1.0 + cx_sqrt(cx_sqrt(0.5))) * 0.5;  // crossfade.rs:5
 __device__ constexpr HannK HANN_W14 = make_hann_k(0.5, 16384, 32);
 __device__ constexpr HannK HANN_E14 = make_hann_k(HANN_ENV_AMP, 8192, 16);
+// synthesis window times -1/(4N) = -2^-16 (hop4: the scale of the magnitudes, src/fft.rs:72's / N and the sign
+// of the negated phasors, moved out of the per-bin stage; a power of two, so nothing rounds differently)
+constexpr double HANN_KAPPA = -0.25 / 16384.0;
+__device__ constexpr HannK HANN_W14K = make_hann_k(0.5 * HANN_KAPPA, 16384, 32);
 
 template <bool PITCH1, bool HANN>
 __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
@@ -1803,6 +1861,553 @@ __global__ __launch_bounds__(256, 3) void hop3_kernel(const HopParams p) {
     }
 }
 
+// =============== v4: hop3's arithmetic, two of the four exchanges wave-local ====================
+// hop3 synchronises the whole workgroup around every half-exchange (14 s_barrier per hop), and its own
+// ablations price that lockstep - all four waves reach the LDS store path together - above the stores
+// themselves. hop4 keeps every register layout and every floating-point operation of hop3 (the output
+// is bit-identical) and changes only WHICH THREAD holds a layout's elements (tests/dev/proto_v4.py is
+// the index model; it checks every hand-over and the bank conflicts of every wave instruction):
+//   * the 16 low nibbles of a residue fall into four classes closed under negation mod 16,
+//     phi(l) = l0 ? 1 + 2 (l1 ^ l2) : 2 l1. A wave owns one class in the F2 / F3 / I1 / I2 layouts, so a
+//     residue r and its partner 512 - r (the two bins of every (j, M - j) pair) sit in one wave, and
+//     the exchanges E2 (F2 -> F3) and E3 (I1 -> I2) never leave the wave: no s_barrier at all - the LDS
+//     executes one wave's instructions in order, only the compiler needs a fence;
+//   * E1 (F1 -> F2) and E4 (I2 -> I3) still cross waves (the global load / store order wants thread =
+//     low sample bits). Each runs in two rounds over the four per-wave regions of the half-size buffer:
+//     round A writes the OWN region and reads all four, round B writes all four and reads the OWN one, so
+//     a region is only ever overwritten by the wave that read it last and the wave-local exchanges in
+//     between need no workgroup barrier either: 3 barriers per cross exchange, 6 per hop.
+// Register strides 64 (+ a lane ^ 16 swizzle on two patterns) and 65 make 15 of the 16 access patterns
+// conflict-free and the last one 2-way on half a wave.
+#ifndef RC_V4
+#define RC_V4 1
+#endif
+constexpr int HOP4_REG = 1040;                    // float2 slots per wave region (16 x 65)
+constexpr int HOP4_XBUF = 4 * HOP4_REG;
+constexpr int HOP4_LDS_FLOAT2 = HOP4_XBUF + 8 + 32 + 256 + 256 + 16 + 24 + 1024;  // 46 048 B
+constexpr int phi_c(int l) { return (l & 1) ? 1 + 2 * (((l >> 1) ^ (l >> 2)) & 1) : 2 * ((l >> 1) & 1); }
+constexpr int cidx_c(int l) { return (((l >> 2) & 1) << 1) | ((l >> 3) & 1); }
+// compiler-only ordering of one wave's LDS accesses (no instruction is emitted)
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroup barrier of the hop loop. __syncthreads() also waits for vmcnt(0), i.e. for the previous hop's
+// output stores to be acknowledged; the exchanges only need this wave's LDS operations to have completed.
+#ifndef RC_LGKM_BARRIER
+#define RC_LGKM_BARRIER 1
+#endif
+#ifndef RC_T_SDST
+#define RC_T_SDST 1
+#endif
+#ifndef RC_T_F1
+#define RC_T_F1 1
+#endif
+#ifndef RC_T_PAIR
+#define RC_T_PAIR 1
+#endif
+#if RC_T_PAIR
+#define HOP4_PAIR pair_regs_pk4
+#else
+#define HOP4_PAIR pair_regs_pk
+#endif
+#define HOP4_BAR()                                                                    \
+    do {                                                                              \
+        if (RC_ABLATE & 32) break;                                                    \
+        if (RC_LGKM_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        else __syncthreads();                                                         \
+    } while (0)
+template <bool PITCH1>
+__global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
+    constexpr int LOG2N = 14, m = 13, M = 1 << m, H = M, T = 256, P = 32, PH = 16;
+    constexpr int RES = 512, REG = HOP4_REG;
+    constexpr int SCR = HOP4_XBUF + 8;
+    constexpr int T_A = SCR + 32;                 // [256] W_8192^r
+    constexpr int T_R = T_A + 256;                // [256] W_16384^r
+    constexpr int T_B = T_R + 256;                // [16]  W_512^l
+    constexpr int T_C = T_B + 16;                 // [24]  W_64^k, k <= 16
+    constexpr int T_H = T_C + 24;                 // [1024] window / envelope rotations
+    static_assert(T_H + 1024 == HOP4_LDS_FLOAT2, "LDS layout");
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int tid = threadIdx.x;
+    uint32_t gr = blockIdx.x;
+    const bool seam = p.seam_head != nullptr;
+    if (seam) {
+        unsigned *slot = reinterpret_cast<unsigned *>(lds + SCR);
+        if (tid == 0) *slot = atomicAdd(p.run_counter, 1u);
+        __syncthreads();
+        gr = *reinterpret_cast<volatile unsigned *>(slot);
+        __syncthreads();
+    }
+    const uint32_t run = gr % p.runs_per_channel;
+    const uint32_t ch = gr / p.runs_per_channel;
+    const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
+    int64_t k_end = k_begin + p.run_len;
+    if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
+    if (k_begin >= k_end) return;
+    const bool stash_first = seam && run > 0;
+    const bool has_next = seam && run + 1 < p.runs_per_channel;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
+    const unsigned lane2 = 2u * (unsigned)tid;
+    GV2 wtab = (GV2)p.wtab;
+    const uint32_t pitch = PITCH1 ? 1u : p.pitch;
+
+    // ---- who am I in each layout. Everything below is a few integer operations on tid; it is recomputed
+    // from an opaque copy right before each exchange instead of living in ~20 VGPRs across the whole hop
+    // (at 168 VGPRs the allocator spilled them, and a scratch reload waits in line behind every older
+    // vector-memory operation of the wave).
+    struct Who {
+        int wv, lane, cc, lo4, nib, r, A0;
+    };
+    auto who = [&]() {
+        int t = tid;
+        opaque(t);
+        Who w;
+        w.wv = t >> 6;
+        w.lane = t & 63;
+        w.cc = (t >> 4) & 3;
+        w.lo4 = t & 15;
+        // nibble of class wv with index cc = (l2 << 1 | l3): member(wv, cc)
+        const int nl3 = w.cc & 1, nl2 = w.cc >> 1, nl0 = w.wv & 1;
+        const int nl1 = nl0 ? ((w.wv >> 1) ^ nl2) : (w.wv >> 1);
+        w.nib = (nl3 << 3) | (nl2 << 2) | (nl1 << 1) | nl0;
+        // F2: l4 = nib, uu = lo4.  F3 / I1: residue r = lo4 << 4 | nib (and 512 - r).  I2: l4' = lo4, uu' = brev4(nib)
+        w.r = (w.lo4 << 4) | w.nib;
+        w.A0 = w.wv * REG + w.lane;
+        return w;
+    };
+    const int wv = tid >> 6;  // (wave-uniform branches only)
+    Stamps st;
+    st.init();
+    v2f tail[PH];
+#pragma unroll
+    for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
+    {
+        lds[T_A + tid] = ldg2(wtab + tid);
+        lds[T_R + tid] = ldg2((GV2)p.rtab + tid);
+        if (tid < 16) lds[T_B + tid] = ldg2(wtab + 16 * tid);
+        if (tid <= 16) lds[T_C + tid] = ldg2(wtab + 128 * tid);
+        if (tid == 0) {  // W_N^(256 - 4096) = i W_N^256: thread 0's twiddle base for its residue-256 slots
+            const float2 w256 = ldg2((GV2)p.rtab + 256);
+            lds[SCR + 2] = make_float2(-w256.y, w256.x);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float2 a = ldg2((GV2)p.hann_rot + 512 * i + 2 * tid);
+            const float2 b = ldg2((GV2)p.hann_rot + 512 * i + 2 * tid + 1);
+            lds[T_H + 512 * i + 2 * tid] = make_float2(a.x, b.x);
+            lds[T_H + 512 * i + 2 * tid + 1] = make_float2(a.y, b.y);
+        }
+        __syncthreads();
+    }
+    const v2f half2 = {0.5f, 0.5f};
+    auto store_head = [&](int64_t kk, const auto &head) {
+        const v2f amp2 = {p.amp, p.amp};
+        // env[i] * amp = amp/2 + c_q (amp cb) + s_q (amp sb): the amplitude rides on the per-thread rotation
+        const v2f cbE = to_v(lds[T_H + 2 * T + 2 * tid]) * amp2, sbE = to_v(lds[T_H + 2 * T + 2 * tid + 1]) * amp2;
+        const v2f halfa = half2 * amp2;
+        const int64_t g0 = kk * (int64_t)H;
+        if constexpr (PITCH1) {
+            // uniform destination in SGPRs + 32-bit lane offset (no 64-bit address arithmetic per store)
+#if RC_T_SDST
+            const unsigned long long da = (unsigned long long)(outc + (g0 - p.out_origin));
+            const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);  // (the builtin returns int:
+            const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));  // widen as unsigned)
+            GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
+#else
+            GFW dst = outc + (g0 - p.out_origin);
+#endif
+            if (RC_ABLATE & 4096) dst = outc + ((g0 - p.out_origin) & 0x3FFFF);  // timing only: 1 MiB target
+            if (RC_ABLATE & 2048) {  // timing only: the same bytes as 8 x 16-byte stores (wrong places)
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v2f oo[PH];
+#pragma unroll
+                for (int q = 0; q < PH; ++q) {
+                    const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
+                                   __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
+                    oo[q] = (head[q] + tail[q]) * er;
+                }
+#pragma unroll
+                for (int q = 0; q < PH; q += 2) {
+                    const v4f o4 = {oo[q].x, oo[q].y, oo[q + 1].x, oo[q + 1].y};
+                    __builtin_nontemporal_store(o4, (v4f RC_AS1 *)(dst + 4 * T * (q / 2) + 2 * lane2));
+                }
+                return;
+            }
+#pragma unroll
+            for (int q = 0; q < PH; ++q) {
+                const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
+                               __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
+                const v2f o = (head[q] + tail[q]) * er;  // (y + tail) * (env * amp), stretcher.rs:97-100
+                if ((RC_ABLATE & 1024) && o.x != 1.2345e-30f) continue;
+#if RC_NTSTORE
+                __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));
+#else
+                *(GV2W)(dst + 2 * T * q + lane2) = o;
+#endif
+            }
+        } else {
+            const int64_t kq = g0 / pitch;
+            const uint32_t kr = (uint32_t)(g0 % pitch);
+            GFW dst = outc + (kq - p.out_origin);
+            int t2 = tid;
+            opaque(t2);
+#pragma unroll
+            for (int q = 0; q < PH; ++q) {
+                const uint32_t i0 = 2u * (uint32_t)(t2 + T * q);
+                const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
+                               __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
+                const v2f o = (head[q] + tail[q]) * er;
+                const uint32_t a0 = kr + i0, a1 = a0 + 1;
+                const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
+                if (d0 * pitch == a0) dst[d0] = o.x;
+                if (d1 * pitch == a1) dst[d1] = o.y;
+            }
+        }
+    };
+    for (int64_t k = ((k_begin > 0 && !stash_first) ? k_begin - 1 : k_begin); k < k_end; ++k) {
+        const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+        v2f v[P];
+        st.mark(26);
+        {   // register brev5(q) := z[q * T + t] * window ; F1 = stages 0..4
+            GF src = hop_src(p, xc, xt, k);
+            float xr0[P], xr1[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                if (RC_ABLATE & 512) {
+                    xr0[q] = (float)(lane2 + q) + (float)k;
+                    xr1[q] = xr0[q] * 0.5f;
+                    continue;
+                }
+                xr0[q] = (src + 2 * T * q)[lane2];
+                xr1[q] = (src + 2 * T * q)[lane2 + 1];
+            }
+            const v2f cb = to_v(lds[T_H + 2 * tid]), sb = to_v(lds[T_H + 2 * tid + 1]);
+#if RC_T_F1
+            // stage 0 pairs registers brev5(q) and brev5(q + 16) = brev5(q) + 1: a +- b with a = x_q w_q and
+            // b = x_{q+16} w_{q+16} is one multiply and two FMAs
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v2f wl = __builtin_elementwise_fma(v2f{HANN_W14.s[q], HANN_W14.s[q]}, sb,
+                               __builtin_elementwise_fma(v2f{HANN_W14.c[q], HANN_W14.c[q]}, cb, half2));
+                const v2f wh = __builtin_elementwise_fma(v2f{HANN_W14.s[q + 16], HANN_W14.s[q + 16]}, sb,
+                               __builtin_elementwise_fma(v2f{HANN_W14.c[q + 16], HANN_W14.c[q + 16]}, cb, half2));
+                const v2f a = v2f{xr0[q], xr1[q]} * wl, xh = v2f{xr0[q + 16], xr1[q + 16]};
+                v[2 * brev_c(q, 4)] = __builtin_elementwise_fma(xh, wh, a);
+                v[2 * brev_c(q, 4) + 1] = __builtin_elementwise_fma(-xh, wh, a);
+            }
+            st.mark(0);
+            dit_stages<32, m, 1, 4, 0, false, false>(v);
+#else
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const v2f wq = __builtin_elementwise_fma(v2f{HANN_W14.s[q], HANN_W14.s[q]}, sb,
+                               __builtin_elementwise_fma(v2f{HANN_W14.c[q], HANN_W14.c[q]}, cb, half2));
+                v[brev_c(q, 5)] = v2f{xr0[q], xr1[q]} * wq;
+            }
+            st.mark(0);
+            dit_stages<32, m, 0, 4, 0, false, false>(v);
+#endif
+            st.mark(1);
+        }
+        // ---- E1 (cross-wave), round A: position bit 4 clear. Own region (last read by this wave in
+        // the previous hop's E4 round B), then everybody reads everywhere.
+        wave_fence();
+        {
+            const Who w = who();
+            const int A0 = w.A0, A1 = w.wv * REG + (w.lane ^ 16);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) lds[((q >> 3) & 1 ? A1 : A0) + q * 64] = to_f2(v[q]);
+        }
+        st.mark(2);
+        HOP4_BAR();
+        st.mark(3);
+        v2f w2[P];  // register = position bits 4..8
+        {
+            const Who w = who();
+            const int b4u = (int)(__brev((unsigned)w.lo4) >> 28), l3 = w.nib >> 3;
+            const int bE1Ae = w.nib * 64 + b4u + 16 * l3, bE1Ao = w.nib * 64 + b4u - 16 * l3;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int bj = brev_c(j, 4), X = bj & 3;
+                w2[2 * j] = to_v(lds[(bj >> 2) * REG + X * 16 + ((X & 1) ? bE1Ao : bE1Ae)]);
+            }
+        }
+        st.mark(4);
+        HOP4_BAR();
+        st.mark(5);
+        // round B: position bit 4 set. Written into the region of the wave that will read it.
+        {
+            int t = tid;
+            opaque(t);
+            // brev4(t >> 4) * 64 + brev4(t & 15)
+            const int bE1Bs = (int)(__brev((unsigned)(t >> 4)) >> 28) * 64 + (int)(__brev((unsigned)(t & 15)) >> 28);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) lds[phi_c(q) * REG + cidx_c(q) * 16 + bE1Bs] = to_f2(v[16 + q]);
+        }
+        st.mark(6);
+        HOP4_BAR();
+        st.mark(7);
+        Who w = who();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w2[2 * j + 1] = to_v(lds[w.A0 + j * 64]);
+        st.mark(8);
+        dit_stages<32, m, 5, 8, 4, false, true>(w2, to_v(lds[T_B + w.nib]));
+        st.mark(9);
+        // ---- E2 (wave-local): position bit 8 clear (residues r), then set (residues 512 - r)
+        wave_fence();
+        v2f va[16], vb[16];
+        {
+            w = who();
+            const int rlow = (256 - w.r) & 255;                       // (512 - r) - 256
+            const int nibb = rlow & 15;                               // its nibble (same class), rho = rlow >> 4
+            const int cb = (((nibb >> 2) & 1) << 1) | (nibb >> 3);    // cidx(nibb)
+            const int bE2A = w.wv * REG + w.lo4 * 65 + w.cc * 16;
+            const int bE2B = w.wv * REG + (rlow >> 4) * 65 + cb * 16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) lds[w.A0 + q * 65] = to_f2(w2[q]);
+            wave_fence();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) va[q] = to_v(lds[bE2A + q]);
+            wave_fence();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) lds[w.A0 + q * 65] = to_f2(w2[16 + q]);
+            wave_fence();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) vb[q] = to_v(lds[bE2B + q]);
+            wave_fence();
+        }
+        st.mark(10);
+        w = who();
+        const int r = w.r;
+        {
+            const v2f wa = to_v(lds[T_A + r]);  // W_8192^r
+            const v2f k16 = {W32_RE[2], W32_IM[2]};
+            v2f wb = vcmul(v2f{wa.x, -wa.y}, k16);  // W_8192^(512 - r); thread 0: rb = 256 -> W_32
+            if (tid == 0) wb = v2f{W32_RE[1], W32_IM[1]};
+            dit_stages<16, m, 9, 12, 9, false, true>(va, wa);
+            dit_stages<16, m, 9, 12, 9, false, true>(vb, wb);
+        }
+        st.mark(11);
+        // ---- middle stage in registers: pair (A[q], B[15 - q]) = bins (r + 512 q, M - that).
+        // Thread 0 owns the two residues that pair with themselves (0 and 256): its 32 bins form 17 pairs,
+        // (512 q, 512 (16 - q)), (256 + 512 i, 256 + 512 (15 - i)) and the self-paired bins 0 and 4096.
+        // Wave 0 re-deals lane 0's registers (v_cndmask, a uniform branch for the other waves) so that the
+        // same 16 slots compute 16 of them - slots 0..7 on residue 0 with bin 0 as slot 0 (dc), slots 8..15
+        // on residue 256 through a second per-lane twiddle base / hash counter - and computes bin 4096 as
+        // one extra pair. (hop2 / hop3 hand these pairs to 17 lanes through an LDS scratch: four dependent
+        // LDS round trips on wave 0 alone, ~4 000 cycles per hop that the other three waves then wait for
+        // at the next barrier.)
+        const bool is0 = tid == 0;
+        v2f s8 = va[8];
+        if (wv == 0) {
+            const v2f va0 = va[0];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const v2f a = va[8 + i], b0 = vb[i], b1 = vb[8 + i];
+                const v2f nx = i < 7 ? va[9 + i] : va0;
+                va[8 + i] = vsel(is0, b0, a);
+                vb[i] = vsel(is0, b1, b0);
+                vb[8 + i] = vsel(is0, nx, b1);
+            }
+        }
+        {
+            const float2 wrl = lds[T_R + r];
+            const float2 wrh = lds[is0 ? SCR + 2 : T_R + r];         // thread 0: W_N^(256 - 4096)
+            const uint32_t x0 = (uint32_t)r * key.mul + key.k0;
+            const uint32_t dx = (uint32_t)RES * key.mul;
+            const uint32_t x0h = x0 - (is0 ? 3840u * key.mul : 0u);   // thread 0: bins 256 + 512 (q - 8)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float2 wr = q < 8 ? wrl : wrh;
+                const v2f wrv = to_v(wr);
+                const v2f wq = q == 0 ? wrv : (q == 8 ? v2f{wr.y, -wr.x}
+                               : vcmul(wrv, v2f{W32_RE[q & 15], W32_IM[q & 15]}));
+                v2f VA, VB;
+                if (q == 0)
+                    HOP4_PAIR<LOG2N, true>(va[q], vb[15 - q], wq, x0, key, VA, VB, is0);
+                else
+                    HOP4_PAIR<LOG2N>(va[q], vb[15 - q], wq, (q < 8 ? x0 : x0h) + (uint32_t)q * dx, key, VA, VB);
+                va[q] = VA;
+                vb[15 - q] = VB;
+            }
+        }
+        st.mark(12);
+        if (wv == 0) {
+            // bin 4096 = M / 2 pairs with itself: exp(-2 pi i 4096 / N) = -i, counter of bin 4096
+            v2f V8, V8b;
+            HOP4_PAIR<LOG2N>(s8, s8, v2f{0.0f, -1.0f}, 8u * (uint32_t)RES * key.mul + key.k0, key, V8, V8b);
+            v2f na[8], nb0[8], nb1[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                na[i] = vsel(is0, i == 0 ? V8 : vb[7 + i], va[8 + i]);  // va[8+i] <- vb'[8 + (i - 1)]
+                nb0[i] = vsel(is0, va[8 + i], vb[i]);                  // vb[i]   <- va'[8 + i]
+                nb1[i] = vsel(is0, vb[i], vb[8 + i]);                  // vb[8+i] <- vb'[i]
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                va[8 + i] = na[i];
+                vb[i] = nb0[i];
+                vb[8 + i] = nb1[i];
+            }
+        }
+        st.mark(13);
+        // ---- inverse: I1 in registers
+        v2f pa[16], pb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            pa[brev_c(q, 4)] = va[q];
+            pb[brev_c(q, 4)] = vb[q];
+        }
+        dit_stages<16, m, 0, 3, 0, true, false>(pa);
+        dit_stages<16, m, 0, 3, 0, true, false>(pb);
+        st.mark(14);
+        // ---- E3 (wave-local): inverse position bit 4 clear (residue r), then set (512 - r)
+        wave_fence();
+        {
+            w = who();
+            const int bE3A = w.wv * REG + w.lo4 * 65 + w.cc * 16;        // l4' * 65 + c * 16, l4' = lo4
+            // round B: element 256 + x, x = brev4(j) << 4 | nib, is held by thread (256 - x) & 255: rho_s =
+            // 15 - brev4(j) and nibble 16 - nib when nib != 0; rho_s = (16 - brev4(j)) & 15, nibble 0 otherwise
+            const int nn = (16 - w.nib) & 15;
+            const int cs3 = (((nn >> 2) & 1) << 1) | (nn >> 3);
+            const int bE3B = w.wv * REG + w.lo4 * 65 + cs3 * 16 + (w.nib == 0 ? 1 : 0);
+            const int bE3B0 = bE3B - (w.nib == 0 ? 16 : 0);              // brev4(j) == 0
+#pragma unroll
+            for (int q = 0; q < 16; ++q) lds[w.A0 + q * 65] = to_f2(pa[q]);
+            wave_fence();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[2 * j] = to_v(lds[bE3A + brev_c(j, 4)]);
+            wave_fence();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) lds[w.A0 + q * 65] = to_f2(pb[q]);
+            wave_fence();
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                v[2 * j + 1] = to_v(lds[(brev_c(j, 4) == 0 ? bE3B0 : bE3B) + 15 - brev_c(j, 4)]);
+            wave_fence();
+        }
+        st.mark(15);
+        w = who();
+        dit_stages<32, m, 4, 8, 4, true, true>(v, to_v(lds[T_B + w.lo4]));
+        st.mark(16);
+        // ---- E4 (cross-wave), round A: inverse position bit 8 clear, own region
+        wave_fence();
+        {
+            w = who();
+            const int A0 = w.A0, A1 = w.wv * REG + (w.lane ^ 16);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) lds[((q & 1) ? A1 : A0) + q * 64] = to_f2(v[q]);
+        }
+        st.mark(17);
+        HOP4_BAR();
+        st.mark(18);
+        v2f y[P];  // register = position bits 8..12
+        {
+            int t = tid;
+            opaque(t);
+            const int rho8 = t >> 4, l4p = t & 15;
+            const int bE4Ae = rho8 * 64 + l4p + 16 * (rho8 & 1), bE4Ao = rho8 * 64 + l4p - 16 * (rho8 & 1);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int nj = brev_c(j, 4), cs = cidx_c(nj);
+                y[2 * j] = to_v(lds[phi_c(nj) * REG + 32 * (cs >> 1) + ((cs & 1) ? bE4Ao + 16 : bE4Ae)]);
+            }
+        }
+        st.mark(19);
+        HOP4_BAR();
+        st.mark(20);
+        // round B: bit 8 set, written into the reader's region
+        {
+            w = who();
+            const int bE4Bs = (int)(__brev((unsigned)w.nib) >> 28) * 64 + w.lo4;  // brev4(nib) * 64 + l4'
+#pragma unroll
+            for (int q = 0; q < 16; ++q) lds[(q >> 2) * REG + (q & 3) * 16 + bE4Bs] = to_f2(v[16 + q]);
+        }
+        st.mark(21);
+        HOP4_BAR();
+        st.mark(22);
+        w = who();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) y[2 * j + 1] = to_v(lds[w.A0 + j * 64]);
+        st.mark(23);
+        dit_stages<32, m, 9, 12, 8, true, true>(y, to_v(lds[T_A + tid]));
+        st.mark(24);
+
+        // ---- epilogue: synthesis window, overlap-add with the carried tail, store
+        const v2f cbW = to_v(lds[T_H + 2 * tid]), sbW = to_v(lds[T_H + 2 * tid + 1]);
+#if RC_T_PAIR
+        const v2f half2k = {(float)(0.5 * HANN_KAPPA), (float)(0.5 * HANN_KAPPA)};
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+            y[q] *= __builtin_elementwise_fma(v2f{HANN_W14K.s[q], HANN_W14K.s[q]}, sbW,
+                    __builtin_elementwise_fma(v2f{HANN_W14K.c[q], HANN_W14K.c[q]}, cbW, half2k));
+#else
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+            y[q] *= __builtin_elementwise_fma(v2f{HANN_W14.s[q], HANN_W14.s[q]}, sbW,
+                    __builtin_elementwise_fma(v2f{HANN_W14.c[q], HANN_W14.c[q]}, cbW, half2));
+#endif
+        if (k >= k_begin) {
+            if (stash_first && k == k_begin) {
+                int t2 = tid;
+                opaque(t2);
+                unsigned long long *hs = (unsigned long long *)(p.seam_head + (size_t)gr * H) + t2;
+#pragma unroll
+                for (int q = 0; q < PH; ++q)
+                    __hip_atomic_store(hs + T * q, __builtin_bit_cast(unsigned long long, y[q]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // every storing wave drains its own write-through stores before the barrier; only then
+                // may lane 0 publish (MI355X_MICROARCH.md, valid hand-off forms)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0 && !(p.diag_flags & RC_DIAG_SKIP_SEAM_PUBLISH))
+                    __hip_atomic_store(p.seam_flag + gr, p.seam_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                store_head(k, y);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PH; ++q) tail[q] = y[q + PH];
+        st.mark(25);
+    }
+#if RC_STAMP
+    if ((tid & 63) == 0 && p.spec) {
+        unsigned *dbg = (unsigned *)p.spec + ((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * 32;
+        for (int i = 0; i < 32; ++i) dbg[i] = st.acc[i];
+    }
+#endif
+    if (has_next) {
+        unsigned *okw = reinterpret_cast<unsigned *>(lds + SCR);
+        if (tid == 0) {
+            unsigned ok = 0;
+            for (unsigned spin = 0; spin < p.seam_spin_limit; ++spin) {
+                if (__hip_atomic_load(p.seam_flag + gr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                    p.seam_epoch) {
+                    ok = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            if (!ok && p.err_word)
+                __hip_atomic_store(p.err_word, RC_ERR_SEAM_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            *okw = ok;
+        }
+        __syncthreads();
+        if (*reinterpret_cast<volatile unsigned *>(okw) == 0) return;
+        const unsigned long long *hs = (const unsigned long long *)(p.seam_head + (size_t)(gr + 1) * H) + tid;
+        v2f head[PH];
+#pragma unroll
+        for (int q = 0; q < PH; ++q)
+            head[q] = __builtin_bit_cast(v2f, __hip_atomic_load(hs + T * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        store_head(k_end, head);
+    }
+}
+
 // Overlap-add for the user-kernel path (gather form, two terms per output sample).
 __global__ __launch_bounds__(256) void ola_kernel(const OlaParams p) {
     const uint32_t N = 1u << p.log2n, H = N / 2;
@@ -1854,7 +2459,11 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
             if (RC_V2 && LOG2N == 14) {
                 const size_t lds2 = sizeof(float2) * (size_t)HOP2_LDS_FLOAT2;
                 const bool hann = p.hann_rot != nullptr;
-                if (RC_V3 && hann) {
+                if (RC_V4 && hann && !(p.diag_flags & RC_DIAG_PREV_KERNEL)) {
+                    const size_t lds4 = sizeof(float2) * (size_t)HOP4_LDS_FLOAT2;
+                    if (p.pitch == 1) hipLaunchKernelGGL((hop4_kernel<true>), grid, block, lds4, s, p);
+                    else hipLaunchKernelGGL((hop4_kernel<false>), grid, block, lds4, s, p);
+                } else if (RC_V3 && hann) {
                     const size_t lds3 = sizeof(float2) * (size_t)HOP3_LDS_FLOAT2;
                     if (p.pitch == 1) hipLaunchKernelGGL((hop3_kernel<true>), grid, block, lds3, s, p);
                     else hipLaunchKernelGGL((hop3_kernel<false>), grid, block, lds3, s, p);

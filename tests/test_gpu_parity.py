@@ -662,6 +662,32 @@ def test_16384_full_length_every_sample_vs_oracle(p):
     assert blk.max() <= 3e-4, (float(blk.max()), np.unravel_index(blk.argmax(), blk.shape))
 
 
+@pytest.mark.parametrize("p", [1, 3])
+def test_hop4_agrees_with_previous_kernel_generation(monkeypatch, p):
+    """hop4_kernel changes which thread holds which elements between passes (wave-local exchanges) and how
+    thread 0's self-paired bins are computed (packed arithmetic in registers instead of the scalar LDS
+    side path); everything else is hop3_kernel's operation for operation (the first hop4, which kept the
+    side path, was bit-identical). hop3 stays in the library behind ROCODER_DIAG=2 for this check and for
+    A/B timing: the two must agree far inside the tolerance (hop4 also fuses the analysis window into the
+    first butterfly stage and folds the amplitude into the envelope, so single roundings differ)."""
+    import torch
+
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, 2_200_000) for c in range(2)])
+    xt = torch.from_numpy(x).cuda()
+    with ra.Engine(window_len=16384, factor=8.0, pitch_multiple=p, channels=2, seed=77) as e:
+        new = e.stretch_tensor(xt).clone()
+        torch.cuda.synchronize()
+    monkeypatch.setenv("ROCODER_DIAG", "2")
+    with ra.Engine(window_len=16384, factor=8.0, pitch_multiple=p, channels=2, seed=77) as e:
+        old = e.stretch_tensor(xt).clone()
+        torch.cuda.synchronize()
+    assert torch.isfinite(new).all() and float(new.abs().max()) > 0.01
+    d = (new.double() - old.double())
+    rel = float(d.pow(2).mean().sqrt() / old.double().pow(2).mean().sqrt())
+    assert rel <= 2e-7, rel
+
+
 def test_seam_wait_expiry_fails_loudly(monkeypatch):
     """The run-seam hand-over of the N = 16384 kernel has a bounded wait. With the diagnostic flag that
     makes producers skip the publish (ROCODER_DIAG=1), consumers must give up, leave a device error

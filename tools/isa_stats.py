@@ -26,6 +26,7 @@ def kernel_lines(path, name):
 
 
 def classify(op):
+    op = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
     if op.startswith("v_pk_"):
         return "valu_pk", 4
     if op in ("v_sin_f32", "v_cos_f32", "v_sqrt_f32", "v_rcp_f32", "v_rsq_f32", "v_exp_f32", "v_log_f32"):
