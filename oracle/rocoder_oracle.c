@@ -356,6 +356,7 @@ static void dq_truncate_front(rco_deque *d, size_t keep) {
 static float *dq_ptr(rco_deque *d) { return d->p + d->off; }
 
 struct rco_stretcher {
+    size_t skip_debt; /* samples of future input to discard (step > buffered length) */
     uint32_t sample_rate;
     uint16_t channels;
     float buffer_secs;
@@ -406,9 +407,8 @@ rco_stretcher *rco_stretcher_new(uint32_t sample_rate, uint16_t channels, float 
         step = (size_t)-1;
     else
         step = (size_t)stepf;
-    /* step > window_len (psf < 0.5): `len - step` at stretcher.rs:105-106 underflows once fewer
-     * than `step` samples remain (panic in debug, wrap + no-op truncate => hang in release). */
-    if (step > window_len) return NULL;
+    /* step > window_len (psf < 0.5, README "-f 0.2 to speed up 5x") is supported: see the
+     * deliberate deviation at the truncate in rco_stretcher_next_window. */
 
     rco_stretcher *s = (rco_stretcher *)calloc(1, sizeof *s);
     s->sample_rate = sample_rate;
@@ -465,7 +465,9 @@ size_t rco_stretcher_max_window_out(const rco_stretcher *s) {
 int rco_stretcher_ensure_input(rco_stretcher *s, size_t n) {
     while (s->input_buf.len < n) {
         if (s->pending.len) {
-            dq_extend(&s->input_buf, dq_ptr(&s->pending), s->pending.len);
+            size_t skip = s->skip_debt < s->pending.len ? s->skip_debt : s->pending.len;
+            s->skip_debt -= skip; /* samples a step larger than the buffer still owes (see next_window) */
+            dq_extend(&s->input_buf, dq_ptr(&s->pending) + skip, s->pending.len - skip);
             s->pending.len = 0;
             s->pending.off = 0;
         } else if (s->input_closed) {
@@ -513,11 +515,18 @@ int rco_stretcher_next_window(rco_stretcher *s, float *out, size_t *n_out) {
         }
         dq_extend(&s->output_buf, fr + H, N - H); /* stretcher.rs:102-103 */
         s->iter_output_buf_pos += H;              /* stretcher.rs:104 */
-        /* stretcher.rs:105-106: truncate_front(len - step). In release builds the
-         * subtraction wraps when step > len and slice-deque treats the huge value as a
-         * no-op; that case never terminates, so it is reported as invalid here. */
-        if (s->sample_step_len > s->input_buf.len) return RCO_EINVAL;
-        dq_truncate_front(&s->input_buf, s->input_buf.len - s->sample_step_len);
+        /* stretcher.rs:105-106: truncate_front(len - step). DELIBERATE DEVIATION for step > len
+         * (only possible when step > window_len, i.e. speed-up factors below 0.5): the reference's
+         * `len - step` underflows there (panic in debug; in release the wrapped value makes the
+         * truncate a no-op and the loop never ends). Here the hop grid stays x[k step .. k step + N):
+         * everything buffered is dropped and the samples still owed are skipped from the input that
+         * arrives later (on a closed channel they are the zero padding of stretcher.rs:129-132). */
+        if (s->sample_step_len > s->input_buf.len) {
+            s->skip_debt += s->sample_step_len - s->input_buf.len;
+            dq_truncate_front(&s->input_buf, 0);
+        } else {
+            dq_truncate_front(&s->input_buf, s->input_buf.len - s->sample_step_len);
+        }
     }
     /* stretcher.rs:108-111 */
     size_t m = rco_resample(dq_ptr(&s->output_buf), S, s->pitch_multiple, out);
@@ -597,7 +606,6 @@ size_t rco_offline_output_len(size_t len, size_t window_len, float factor, int p
     float psf = pitch_multiple < 0 ? factor / abs_p : factor * abs_p;
     float stepf = (float)window_len / (psf * 2.0f);
     if (!(stepf >= 1.0f)) return 0;
-    if (stepf > (float)window_len) return 0;
     size_t step = (size_t)stepf;
     size_t H = window_len / 2;
     size_t S = pitch_multiple < 0 ? (size_t)ceilf((float)window_len / abs_p)

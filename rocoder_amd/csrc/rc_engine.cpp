@@ -90,8 +90,11 @@ int derive(const rc_config *c, rc_params *o) {
     const float stepf = (float)c->window_len / (psf * 2.0f);
     if (!(stepf >= 1.0f))
         return fail(RC_EINVAL, "sample_step_len == 0: the reference never terminates (src/stretcher.rs:55,105-106)");
-    if (stepf > (float)c->window_len)
-        return fail(RC_EINVAL, "sample_step_len > window_len: `len - step` underflows in the reference (src/stretcher.rs:105-106)");
+    // stepf > window_len (factors below 0.5: README "-f 0.2 to speed up 5x") is supported: hop k still reads
+    // x[k step .. k step + N) and the stream ends at the first hop whose window runs past the input, the
+    // samples between two windows are skipped. (The reference's `len - step` at src/stretcher.rs:105-106
+    // underflows once fewer than `step` samples are buffered - a panic or an endless loop at the end of
+    // every such file; a deliberate fix, mirrored by the oracle.)
     o->window_len = c->window_len;
     o->half_window_len = H;
     o->samples_needed_per_window = S;

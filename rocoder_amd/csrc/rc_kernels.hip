@@ -1899,6 +1899,10 @@ __device__ __forceinline__ void wave_fence() {
 #ifndef RC_LGKM_BARRIER
 #define RC_LGKM_BARRIER 1
 #endif
+// number of output pairs of a hop (of 16) whose store is deferred into the next hop's first pass; 0 = none
+#ifndef RC_DEFER_STORE
+#define RC_DEFER_STORE 0
+#endif
 #ifndef RC_T_SDST
 #define RC_T_SDST 1
 #endif
@@ -2069,6 +2073,28 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             }
         }
     };
+    // Deferred output stores (pitch 1). A CU drains about 11 bytes per clock towards memory: the 8 KiB a wave
+    // writes per hop take ~750 cycles, and the four waves of a workgroup reach their epilogues together, so 16
+    // back-to-back stores stall a wave for ~2 500 cycles at issue (timing-only builds without the stores run
+    // 9 % faster, with 16-byte stores or an L2-resident target no faster). The epilogue therefore only
+    // computes the 16 output pairs; they are stored one or two at a time between the butterflies of the NEXT
+    // hop's first pass, behind that hop's input loads in issue order (loads no longer queue behind stores).
+    constexpr int DN = RC_DEFER_STORE;  // output pairs [PH - DN, PH) of a hop are stored during the next hop
+    constexpr bool DEFER = PITCH1 && DN > 0;
+    constexpr int D0 = PH - (DN > 0 ? DN : PH);
+    v2f od[DN > 0 ? DN : 1];
+    bool pend = false;
+    int64_t pend_k = 0;
+    auto emit = [&](int q0, int q1) {
+        if (!DEFER || !pend) return;
+        const unsigned long long da = (unsigned long long)(outc + (pend_k * (int64_t)H - p.out_origin));
+        const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);
+        const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
+        GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
+#pragma unroll
+        for (int q = q0; q < q1; ++q)
+            if (q >= D0) __builtin_nontemporal_store(od[q - D0], (GV2W)(dst + 2 * T * q + lane2));
+    };
     for (int64_t k = ((k_begin > 0 && !stash_first) ? k_begin - 1 : k_begin); k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         v2f v[P];
@@ -2099,9 +2125,22 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
                 const v2f a = v2f{xr0[q], xr1[q]} * wl, xh = v2f{xr0[q + 16], xr1[q + 16]};
                 v[2 * brev_c(q, 4)] = __builtin_elementwise_fma(xh, wh, a);
                 v[2 * brev_c(q, 4) + 1] = __builtin_elementwise_fma(-xh, wh, a);
+                if (q & 1) emit(q / 2, q / 2 + 1);
             }
             st.mark(0);
-            dit_stages<32, m, 1, 4, 0, false, false>(v);
+            if (DEFER) {
+                dit_stages<32, m, 1, 1, 0, false, false>(v);
+                emit(8, 10);
+                dit_stages<32, m, 2, 2, 0, false, false>(v);
+                emit(10, 12);
+                dit_stages<32, m, 3, 3, 0, false, false>(v);
+                emit(12, 14);
+                dit_stages<32, m, 4, 4, 0, false, false>(v);
+                emit(14, 16);
+                pend = false;
+            } else {
+                dit_stages<32, m, 1, 4, 0, false, false>(v);
+            }
 #else
 #pragma unroll
             for (int q = 0; q < P; ++q) {
@@ -2367,6 +2406,24 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
                 __syncthreads();
                 if (tid == 0 && !(p.diag_flags & RC_DIAG_SKIP_SEAM_PUBLISH))
                     __hip_atomic_store(p.seam_flag + gr, p.seam_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (DEFER) {
+                const v2f amp2 = {p.amp, p.amp};
+                const v2f cbE = to_v(lds[T_H + 2 * T + 2 * tid]) * amp2, sbE = to_v(lds[T_H + 2 * T + 2 * tid + 1]) * amp2;
+                const v2f halfa = half2 * amp2;
+                const unsigned long long da = (unsigned long long)(outc + (k * (int64_t)H - p.out_origin));
+                const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);
+                const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
+                GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
+#pragma unroll
+                for (int q = 0; q < PH; ++q) {
+                    const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
+                                   __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
+                    const v2f o = (y[q] + tail[q]) * er;  // (y + tail) * (env * amp), stretcher.rs:97-100
+                    if (q < D0) __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));
+                    else od[q - D0] = o;
+                }
+                pend = true;
+                pend_k = k;
             } else {
                 store_head(k, y);
             }
@@ -2375,6 +2432,7 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
         for (int q = 0; q < PH; ++q) tail[q] = y[q + PH];
         st.mark(25);
     }
+    emit(0, PH);  // the last hop's outputs
 #if RC_STAMP
     if ((tid & 63) == 0 && p.spec) {
         unsigned *dbg = (unsigned *)p.spec + ((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * 32;

@@ -46,7 +46,7 @@ def test_derive_params_matches_oracle(N, f, p, a):  # src/stretcher.rs:40-56
 
 
 @pytest.mark.parametrize("bad", [dict(pitch_multiple=0), dict(factor=200.0, window_len=256),
-                                 dict(factor=0.25, window_len=256), dict(pitch_multiple=-1),
+                                 dict(pitch_multiple=-1),
                                  dict(window_len=1), dict(channels=0)])
 def test_invalid_parameters_rejected(bad):
     with pytest.raises(_lib.RocoderError) as ei:

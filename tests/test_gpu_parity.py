@@ -75,6 +75,8 @@ def test_one_hop_golden(goldens):  # ReFFT seam: src/fft.rs:42-74
     (512, 4000, 0.5, 1, 1), (1024, 20000, 8.0, 3, 2), (2048, 30000, 4.0, 1, 1),
     (4096, 50000, 8.0, 1, 2), (8192, 70000, 3.0, 2, 1), (16384, 150000, 8.0, 1, 2),
     (16384, 120000, 8.0, 3, 2), (16384, 100000, 1.0, 1, 1),
+    # speed-up factors below 0.5 (sample_step_len > window_len, README "-f 0.2"): see DESIGN.md §8
+    (1024, 60000, 0.2, 1, 2), (16384, 600000, 0.25, 1, 1), (512, 20000, 0.1, 2, 1), (32768, 500000, 0.25, 1, 1),
 ])
 def test_stretch_matches_oracle(N, L, f, p, ch):
     ra = _engine_mod()
@@ -345,6 +347,23 @@ def test_stretcher_windows_match_oracle_streaming():
         wins_o.append(o.next_window())
     assert len(wins_g) == len(wins_o)
     assert_parity(np.concatenate(wins_g), np.concatenate(wins_o), "streaming windows")
+
+
+def test_streaming_speedup_factor_below_half():
+    """sample_step_len > window_len through the streaming seam (push / next_window), ragged chunks."""
+    ra = _engine_mod()
+    x = onp.synth_input(0, 90000)
+    w = oc.hanning(1024)
+    q: "queue.Queue" = queue.Queue()
+    s = ra.Stretcher(ra.AudioSpec(1, 44100), q, 0.2, 1.0, 1, w, seed=5)
+    for i in range(0, x.size, 7001):
+        q.put(x[i:i + 7001])
+    q.put(None)
+    wins = []
+    while not s.is_done():
+        wins.append(s.next_window().copy())
+    ref = oc.stretch_offline(x[None], 1024, 0.2, 1.0, 1, seed=5)[0]
+    assert_parity(np.concatenate(wins), ref, "f=0.2 streaming")
 
 
 def test_stretcher_processor_equals_offline():

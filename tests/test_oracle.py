@@ -122,8 +122,9 @@ def test_invalid_parameters_rejected():
         oc.Stretcher(pitch_multiple=0, window=w)
     with pytest.raises(ValueError):  # step == 0: the reference loops forever (stretcher.rs:55,105)
         oc.Stretcher(factor=200.0, pitch_multiple=1, window=w)
-    with pytest.raises(ValueError):  # step > N: `len - step` underflow (stretcher.rs:105-106)
-        oc.Stretcher(factor=0.25, pitch_multiple=1, window=w)
+    # step > N (factor < 0.5) is supported: the reference's end-of-file underflow at stretcher.rs:105-106
+    # is deliberately fixed (test_speedup_factors_below_half)
+    assert oc.Stretcher(factor=0.25, pitch_multiple=1, window=w).step == 512
 
 
 # ------------------------------------------------------------------ phase source spec
@@ -373,3 +374,36 @@ def test_cpu_baseline_matches_oracle(N, L, f, p, ch):
     assert one.shape == ref.shape
     assert np.array_equal(one, many)  # hop ranges recompute their predecessor: same bits
     assert rms(one.astype(np.float64) - ref) <= 1e-6 * max(rms(ref), 1e-3)
+
+
+@pytest.mark.parametrize("N,L,f,p", [(256, 5000, 0.25, 1), (1024, 30000, 0.2, 1), (512, 9000, 0.1, 2),
+                                     (256, 700, 0.1, 1)])
+def test_speedup_factors_below_half(N, L, f, p):
+    """README: "-f 0.2 to speed up 5x": sample_step_len > window_len. Hop k reads x[k step .. k step + N)
+    (the samples between two windows are skipped) and the stream ends at the first hop whose window runs past
+    the input - the reference's `len - step` underflow at the end of such a file (stretcher.rs:105-106) is a
+    deliberate fix. C oracle == numpy literal loop == numpy closed form, one chunk or many."""
+    x = onp.synth_input(0, L)
+    d = onp.derive(N, f, 1.0, p)
+    assert d["step"] > N
+    ref = oc.stretch_offline(x[None], N, f, 1.0, p, seed=4)[0]
+    lit = onp.stretch_channel_literal(x, N, f, 1.0, p, 4, 0)
+    clo = onp.stretch_channel_closed(x, N, f, 1.0, p, 4, 0)
+    assert ref.size == lit.size == clo.size == oc.offline_output_len(L, N, f, p)
+    assert rms(ref - lit) <= 2e-6 * rms(lit) + 1e-7 and rms(lit - clo) <= 1e-9
+    s = oc.Stretcher(factor=f, pitch_multiple=p, window=oc.hanning(N), seed=4, channels=1)
+    wins, pos = [], 0
+    for sz in (100, 1, 777, 50, 3000, 10 ** 9):  # chunks smaller than a step leave a skip debt
+        s.send(x[pos:pos + sz])
+        pos += sz
+        while True:
+            try:
+                wins.append(s.next_window())
+            except BlockingIOError:
+                break
+        if pos >= L:
+            break
+    s.close_input()
+    while not s.is_done():
+        wins.append(s.next_window())
+    assert np.array_equal(np.concatenate(wins), ref)
