@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 1
+#define RC_ABI_VERSION 2
 
 /* status codes */
 #define RC_OK 0
@@ -65,7 +65,27 @@ typedef struct rc_config {
     rc_freq_kernel kernel;   /* --freq-kernel; NULL = none */
     void *kernel_user;
     uint64_t kernel_time_ms; /* 0 = wall clock (src/fft.rs:89-92); non-zero = fixed (tests) */
+    /* Host threads that call `kernel`: 0 or 1 = one thread and the reference's call order (windows outer,
+     * channels inner: src/stretcher_processor.rs:63-70). n > 1 = the channels are dealt to up to n threads;
+     * each channel still sees its hops in order, but calls of different channels interleave, so `kernel`
+     * must be re-entrant and must not carry state across channels. */
+    uint32_t kernel_threads;
+    /* Curated frequency kernels that run on the GPU: the spectrum never leaves the device.
+     * They take the place of `kernel` (setting both is RC_EINVAL). All act on the N-bin spectrum X of a hop
+     * like an apply() would, Y = K(X), before |Y| is taken (src/fft.rs:42-48,67):
+     *   RC_DK_GAIN   Y[j] = dk_gain X[j]                      (README.md:121-128 with any factor)
+     *   RC_DK_BAND   Y[j] = (dk_lo_bin <= min(j, N - j) <= dk_hi_bin ? dk_gain : dk_gain_outside) X[j]
+     *   RC_DK_SHIFT  Y[j] = X[j - dk_shift_bins] for 0 <= j <= N/2 (0 where j - shift leaves [0, N/2]),
+     *                Y[N - j] = conj(Y[j]) : the spectrum of a real signal moved up or down by whole bins */
+    uint32_t device_kernel;
+    float dk_gain, dk_gain_outside;
+    uint32_t dk_lo_bin, dk_hi_bin;
+    int32_t dk_shift_bins;
 } rc_config;
+#define RC_DK_NONE 0
+#define RC_DK_GAIN 1
+#define RC_DK_BAND 2
+#define RC_DK_SHIFT 3
 
 /* Values derived in Stretcher::new (src/stretcher.rs:40-56). */
 typedef struct rc_params {

@@ -35,7 +35,17 @@ class rc_config(C.Structure):
         ("kernel", FREQ_KERNEL),
         ("kernel_user", C.c_void_p),
         ("kernel_time_ms", C.c_uint64),
+        ("kernel_threads", C.c_uint32),
+        ("device_kernel", C.c_uint32),
+        ("dk_gain", C.c_float),
+        ("dk_gain_outside", C.c_float),
+        ("dk_lo_bin", C.c_uint32),
+        ("dk_hi_bin", C.c_uint32),
+        ("dk_shift_bins", C.c_int32),
     ]
+
+
+RC_DK_NONE, RC_DK_GAIN, RC_DK_BAND, RC_DK_SHIFT = 0, 1, 2, 3
 
 
 class rc_params(C.Structure):

@@ -283,7 +283,7 @@ struct KernelStack {
     std::string src;
     std::thread watcher;
     std::atomic<bool> stop{false};
-    time_t last_mtime = 0;
+    struct timespec last_mtime {};  // nanosecond mtime: an edit in the same second as the last build counts
 
     static bool is_source(const std::string &p) {
         auto ends = [&](const char *s) { const size_t n = strlen(s); return p.size() >= n && p.compare(p.size() - n, n, s) == 0; };
@@ -333,14 +333,15 @@ struct KernelStack {
             return;
         }
         struct stat st;
-        if (stat(path.c_str(), &st) == 0) last_mtime = st.st_mtime;
+        if (stat(path.c_str(), &st) == 0) last_mtime = st.st_mtim;
         compile_and_load();  // hotswapper.rs:17 (synchronous first attempt)
         watcher = std::thread([this] {
             while (!stop.load()) {
                 std::this_thread::sleep_for(std::chrono::milliseconds(100));  // hotswapper.rs:12,29
                 struct stat st2;
-                if (stat(src.c_str(), &st2) == 0 && st2.st_mtime != last_mtime) {
-                    last_mtime = st2.st_mtime;
+                if (stat(src.c_str(), &st2) == 0 && (st2.st_mtim.tv_sec != last_mtime.tv_sec ||
+                                                     st2.st_mtim.tv_nsec != last_mtime.tv_nsec)) {
+                    last_mtime = st2.st_mtim;
                     compile_and_load();
                 }
             }
@@ -489,6 +490,8 @@ struct Opt {  // src/main.rs:27-122
     std::optional<std::string> input;
     bool rotate_channels = false;
     std::optional<std::string> freq_kernel;
+    std::optional<std::string> device_kernel;  // not in the reference: curated on-GPU kernels
+    int kernel_threads = 0;
     uint64_t fade_ms = 1000;
     std::optional<uint64_t> start_ms, duration_ms;
     std::optional<std::string> output;
@@ -511,6 +514,8 @@ void usage() {
             "    -p, --pitch_multiple <n>           A non-zero integer pitch multiplier [default: 1]\n"
             "    -s, --start <start>                Start time in input audio (hh:mm:ss.ss)\n"
             "    -w, --window <window-len>          Processing window size [default: 16384]\n"
+            "        --device-kernel <spec>         On-GPU frequency kernel: gain:<g> | band:<lo>:<hi>:<g_in>:<g_out> | shift:<bins>\n"
+            "        --kernel-threads <n>           Host threads calling --freq-kernel (channels in parallel; needs a re-entrant kernel)\n"
             "        --seed <u64>                   Phase-source seed (the reference uses an unseeded thread_rng)\n"
             "        --device <n>                   HIP device ordinal [default: 0]\n");
 }
@@ -554,6 +559,8 @@ int run(int argc, char **argv) {
         else if (a == "-i" || a == "--input") o.input = need(i);
         else if (a == "--rotate-channels") o.rotate_channels = true;
         else if (a == "--freq-kernel") o.freq_kernel = need(i);
+        else if (a == "--device-kernel") o.device_kernel = need(i);
+        else if (a == "--kernel-threads") o.kernel_threads = atoi(need(i).c_str());
         else if (a == "-x" || a == "--fade") o.fade_ms = dur(need(i));
         else if (a == "-s" || a == "--start") o.start_ms = dur(need(i));
         else if (a == "-d" || a == "--duration") o.duration_ms = dur(need(i));
@@ -592,6 +599,32 @@ int run(int argc, char **argv) {
     cfg.device = o.device;
     cfg.kernel = o.freq_kernel ? &KernelStack::trampoline : nullptr;
     cfg.kernel_user = &kernels;
+    cfg.kernel_threads = (uint32_t)std::max(0, o.kernel_threads);
+    if (o.device_kernel) {
+        std::vector<std::string> f;
+        size_t b = 0;
+        for (;;) {
+            const size_t c = o.device_kernel->find(':', b);
+            f.push_back(o.device_kernel->substr(b, c == std::string::npos ? c : c - b));
+            if (c == std::string::npos) break;
+            b = c + 1;
+        }
+        if (f[0] == "gain" && f.size() == 2) {
+            cfg.device_kernel = RC_DK_GAIN;
+            cfg.dk_gain = strtof(f[1].c_str(), nullptr);
+        } else if (f[0] == "band" && f.size() == 5) {
+            cfg.device_kernel = RC_DK_BAND;
+            cfg.dk_lo_bin = (uint32_t)strtoul(f[1].c_str(), nullptr, 10);
+            cfg.dk_hi_bin = (uint32_t)strtoul(f[2].c_str(), nullptr, 10);
+            cfg.dk_gain = strtof(f[3].c_str(), nullptr);
+            cfg.dk_gain_outside = strtof(f[4].c_str(), nullptr);
+        } else if (f[0] == "shift" && f.size() == 2) {
+            cfg.device_kernel = RC_DK_SHIFT;
+            cfg.dk_shift_bins = atoi(f[1].c_str());
+        } else {
+            throw std::runtime_error("bad --device-kernel " + *o.device_kernel);
+        }
+    }
     auto eng = std::make_shared<Engine>();
     if (rc_engine_create(&cfg, &eng->h) != RC_OK) throw std::runtime_error(std::string("rocoder_hip: ") + rc_last_error());
 

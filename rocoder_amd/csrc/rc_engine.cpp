@@ -16,6 +16,7 @@
 #include <deque>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -79,6 +80,9 @@ int derive(const rc_config *c, rc_params *o) {
     if (c->pitch_multiple == -1)
         return fail(RC_EINVAL, "pitch_multiple -1 panics in resampler::resample (src/resampler.rs:11)");
     if (c->window_len < 2) return fail(RC_EINVAL, "window_len < 2");
+    if (c->device_kernel > RC_DK_SHIFT) return fail(RC_EINVAL, "unknown device_kernel %u", c->device_kernel);
+    if (c->device_kernel != RC_DK_NONE && c->kernel)
+        return fail(RC_EINVAL, "a device kernel takes the place of the host frequency kernel: set one of them");
     if (c->channels == 0) return fail(RC_EINVAL, "channels == 0");
     const float abs_p = (float)std::abs(c->pitch_multiple);
     const float psf = c->pitch_multiple < 0 ? c->factor / abs_p : c->factor * abs_p;
@@ -175,7 +179,7 @@ struct rc_engine {
     int n_cu = 256;
     std::vector<Channel> ch;
     // scratch
-    DevBuf d_in, d_out, d_spec, d_ybuf, d_ysub, d_tail, d_hop_in, d_hop_out, d_xtail;
+    DevBuf d_in, d_out, d_spec, d_spec2, d_ybuf, d_ysub, d_tail, d_hop_in, d_hop_out, d_xtail;
     // seam hand-over between the runs of hop3_kernel (HopParams::seam_*): stash [runs][H], one flag
     // per run (compared with seam_epoch, so it is zeroed only when it is (re)allocated), run counter
     DevBuf d_seam_head, d_seam_flag, d_run_counter;
@@ -248,6 +252,13 @@ void plan_runs(const rc_engine *e, uint32_t n_channels, int64_t hop_count, uint3
     *run_len = (uint32_t)len;
 }
 
+// corrected_amp_factor (src/stretcher.rs:52), times |g| under RC_DK_GAIN: |g X| = |g| |X| and everything after
+// the magnitude is linear, so the gain rides on the amplitude factor of every overlap-add and the fused
+// kernels run unchanged (the README's x2.0 kernel costs nothing)
+float amp_of(const rc_engine *e) {
+    return e->par.corrected_amp_factor * (e->cfg.device_kernel == RC_DK_GAIN ? fabsf(e->cfg.dk_gain) : 1.0f);
+}
+
 rc::HopParams base_params(const rc_engine *e) {
     rc::HopParams p{};
     p.window = e->d_window;
@@ -255,7 +266,7 @@ rc::HopParams base_params(const rc_engine *e) {
     p.hann_rot = e->d_hann_rot;
     p.wtab = e->d_wtab;
     p.rtab = e->d_rtab;
-    p.amp = e->par.corrected_amp_factor;
+    p.amp = amp_of(e);
     p.step = e->par.sample_step_len;
     p.pitch = (uint32_t)std::max(1, e->cfg.pitch_multiple);
     p.seed_mixed = e->seed_mixed;
@@ -393,17 +404,30 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
     auto back = [&](int i, int64_t k0, int64_t kc) -> int {  // apply() here, then H2D .. OLA on kb
         const int set = i & 1;
         RC_HIP(hipEventSynchronize(kp.ev_fwd[set]));
-        for (int64_t w0 = 0; w0 < kc; w0 += hpw) {
-            for (uint32_t c = 0; c < n_channels; ++c) {
-                for (int64_t h = w0; h < std::min<int64_t>(w0 + hpw, kc); ++h) {
-                    const size_t off = ((size_t)c * kc + h) * N * 2;
-                    // src/fft.rs:86-99: apply(now_ms, bins) -> bins
-                    const int krc = e->cfg.kernel(now_ms(e), kp.h_in[set] + off, kp.h_out[set] + off, N,
-                                                  e->cfg.kernel_user);
-                    // non-zero == panic: keep the unmodified spectrum (src/fft.rs:100-106)
-                    if (krc != 0) memcpy(kp.h_out[set] + off, kp.h_in[set] + off, (size_t)N * 2 * sizeof(float));
+        // channels [c0, c1): windows outer, channels inner, hops of a window innermost
+        auto apply_range = [&](uint32_t c0, uint32_t c1) {
+            for (int64_t w0 = 0; w0 < kc; w0 += hpw) {
+                for (uint32_t c = c0; c < c1; ++c) {
+                    for (int64_t h = w0; h < std::min<int64_t>(w0 + hpw, kc); ++h) {
+                        const size_t off = ((size_t)c * kc + h) * N * 2;
+                        // src/fft.rs:86-99: apply(now_ms, bins) -> bins
+                        const int krc = e->cfg.kernel(now_ms(e), kp.h_in[set] + off, kp.h_out[set] + off, N,
+                                                      e->cfg.kernel_user);
+                        // non-zero == panic: keep the unmodified spectrum (src/fft.rs:100-106)
+                        if (krc != 0) memcpy(kp.h_out[set] + off, kp.h_in[set] + off, (size_t)N * 2 * sizeof(float));
+                    }
                 }
             }
+        };
+        const uint32_t nthr = std::min<uint32_t>(std::max<uint32_t>(1, e->cfg.kernel_threads), n_channels);
+        if (nthr <= 1) {
+            apply_range(0, n_channels);  // the reference's single DSP thread and call order
+        } else {  // rc_config::kernel_threads: channels dealt to threads, per-channel hop order kept
+            std::vector<std::thread> pool;
+            for (uint32_t t = 1; t < nthr; ++t)
+                pool.emplace_back(apply_range, n_channels * t / nthr, n_channels * (t + 1) / nthr);
+            apply_range(0, n_channels / nthr);
+            for (auto &th : pool) th.join();
         }
         RC_HIP(hipMemcpyAsync(kp.d_spec[set].p, kp.h_out[set], (size_t)kc * hop_bytes,
                               hipMemcpyHostToDevice, kp.kb));
@@ -424,7 +448,7 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
         o.out_stride = out_stride;
         o.out_origin = out_origin;
         o.env = e->d_env;
-        o.amp = e->par.corrected_amp_factor;
+        o.amp = amp_of(e);
         o.pitch = e->cfg.pitch_multiple;
         o.samples_needed = (uint32_t)e->par.samples_needed_per_window;
         o.window_out_len = e->par.window_out_len;
@@ -524,7 +548,9 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
             p.tail_hop_first = k_t;
         }
     }
-    const bool fused = !e->cfg.kernel && e->log2n <= 14 && e->cfg.pitch_multiple >= 1;
+    // RC_DK_BAND / RC_DK_SHIFT act on the spectrum between analysis and resynthesis: unfused, but on the device
+    const bool devk = e->cfg.device_kernel == RC_DK_BAND || e->cfg.device_kernel == RC_DK_SHIFT;
+    const bool fused = !e->cfg.kernel && !devk && e->log2n <= 14 && e->cfg.pitch_multiple >= 1;
     if (fused) {
         p.hop_first = hop_first;
         p.hop_count = hop_count;
@@ -604,7 +630,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     // streaming batches do not depend on call history.
     const bool big = e->log2n > 14;
     const uint32_t hpw = e->par.hops_per_window;
-    const size_t per_hop = (size_t)N * 12;  // spectrum / quarter-FFT scratch, y
+    const size_t per_hop = (size_t)N * (devk ? 28 : 12);  // spectrum(s) / quarter-FFT scratch, y
     int64_t chunk_max = (int64_t)(((size_t)1024 << 20) / (per_hop * n_channels));
     chunk_max = std::max<int64_t>(hpw, std::min<int64_t>(chunk_max / hpw * hpw, 32768));
     int rc = e->d_tail.reserve((size_t)e->cfg.channels * H * sizeof(float));
@@ -617,7 +643,8 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     auto run_chunk = [&](int64_t k0, int64_t kc, bool tail_only) -> int {
         int rcc;
         const size_t spec_floats = (size_t)n_channels * kc * N * 2;
-        if (!big && (rcc = e->d_spec.reserve(spec_floats * sizeof(float)))) return rcc;
+        if ((!big || devk) && (rcc = e->d_spec.reserve(spec_floats * sizeof(float)))) return rcc;
+        if (e->cfg.device_kernel == RC_DK_SHIFT && (rcc = e->d_spec2.reserve(spec_floats * sizeof(float)))) return rcc;
         if ((rcc = e->d_ybuf.reserve((size_t)n_channels * kc * N * sizeof(float)))) return rcc;
         rc::HopParams q = p;
         q.spec = (float2 *)e->d_spec.p;
@@ -639,7 +666,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
 #ifndef RC_BIGCR
 #define RC_BIGCR 1
 #endif
-        if (RC_BIGCR && big && e->cfg.pitch_multiple >= 1) {
+        if (RC_BIGCR && big && !devk && e->cfg.pitch_multiple >= 1) {
             // stage C with the overlap-add fused: runs of hops per quarter, tail in registers; the
             // tail of the chunk's last hop goes to a staging buffer and replaces d_tail afterwards
             // (the first run of this very launch still reads the old one)
@@ -652,7 +679,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
             c.out_stride = out_stride;
             c.out_origin = out_origin;
             c.env = e->d_env;
-            c.amp = e->par.corrected_amp_factor;
+            c.amp = amp_of(e);
             c.pitch = (uint32_t)e->cfg.pitch_multiple;
             c.tail_in = (const float *)e->d_tail.p + (size_t)ch_first * H;
             c.tail_out = (float *)e->d_tail_stage.p + (size_t)ch_first * H;
@@ -667,6 +694,36 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
                                   (size_t)n_channels * H * sizeof(float), hipMemcpyDeviceToDevice, s));
             launches += 3;
             return RC_OK;
+        } else if (devk) {
+            // analysis -> curated device kernel on the N-bin spectra -> resynthesis; nothing leaves the GPU
+            if (big) {
+                RC_HIP(rc::launch_big(0, b, s));
+                RC_HIP(rc::launch_big(1, b, s, rc::MODE_FORWARD));
+            } else {
+                RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, q, s));
+            }
+            rc::DevKernelParams d{};
+            d.in = (const float2 *)e->d_spec.p;
+            d.out = e->cfg.device_kernel == RC_DK_SHIFT ? (float2 *)e->d_spec2.p : (float2 *)e->d_spec.p;
+            d.log2n = (uint32_t)e->log2n;
+            d.kind = e->cfg.device_kernel;
+            d.gain_in = e->cfg.dk_gain;
+            d.gain_out = e->cfg.dk_gain_outside;
+            d.lo_bin = e->cfg.dk_lo_bin;
+            d.hi_bin = e->cfg.dk_hi_bin;
+            d.shift = e->cfg.dk_shift_bins;
+            d.hops_total = (uint64_t)n_channels * (uint64_t)kc;
+            RC_HIP(rc::launch_dev_kernel(d, s));
+            q.spec = d.out;
+            b.spec = d.out;
+            if (big) {
+                RC_HIP(rc::launch_big(1, b, s, rc::MODE_RESYNTH));
+                RC_HIP(rc::launch_big(2, b, s));
+                launches += 5;
+            } else {
+                RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, q, s));
+                launches += 3;
+            }
         } else if (big) {
             for (int stage = 0; stage < 3; ++stage) RC_HIP(rc::launch_big(stage, b, s));
             launches += 3;
@@ -682,7 +739,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         o.out_stride = out_stride;
         o.out_origin = out_origin;
         o.env = e->d_env;
-        o.amp = e->par.corrected_amp_factor;
+        o.amp = amp_of(e);
         o.pitch = e->cfg.pitch_multiple;
         o.samples_needed = (uint32_t)e->par.samples_needed_per_window;
         o.window_out_len = e->par.window_out_len;
@@ -947,6 +1004,7 @@ void rc_engine_destroy(rc_engine *e) {
     e->d_in.release();
     e->d_out.release();
     e->d_spec.release();
+    e->d_spec2.release();
     e->d_ybuf.release();
     e->d_ysub.release();
     e->d_tail.release();
@@ -1049,6 +1107,10 @@ int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out
         // (src/stretcher_processor.rs:34, src/stretcher.rs:82-85) unless the whole input is known
         uint64_t max_win = std::max<uint64_t>(1, max_hops / hpw);
         if (!c.closed) max_win = std::min<uint64_t>(max_win, std::max<size_t>(1, rc_engine_channel_bound(e)));
+        // a host frequency kernel may be stateful: no look-ahead, so that the processor's round-robin over the
+        // channels (src/stretcher_processor.rs:63-70: windows outer, channels inner) is also the order in
+        // which apply() sees the hops
+        if (e->cfg.kernel) max_win = 1;
         nwin = std::min<uint64_t>(nwin, max_win);
         const uint64_t hop_count = nwin * hpw;
         // input span: from the hop before k0 (its tail is recomputed) unless a user kernel
@@ -1252,6 +1314,23 @@ int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float 
         RC_HIP(hipStreamSynchronize(e->stream));
         if (e->cfg.kernel(now_ms(e), e->h_spec.data(), e->h_spec2.data(), N, e->cfg.kernel_user) == 0)
             RC_HIP(hipMemcpyAsync(e->d_hop_out.p, e->h_spec2.data(), (size_t)N * 2 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    }
+    if (e->cfg.device_kernel != RC_DK_NONE) {
+        if ((rc = e->d_spec2.reserve((size_t)N * 2 * sizeof(float)))) return rc;
+        rc::DevKernelParams d{};
+        d.in = (const float2 *)e->d_hop_out.p;
+        d.out = e->cfg.device_kernel == RC_DK_SHIFT ? (float2 *)e->d_spec2.p : (float2 *)e->d_hop_out.p;
+        d.log2n = (uint32_t)e->log2n;
+        const bool gain = e->cfg.device_kernel == RC_DK_GAIN;  // (the offline paths fold it into amp)
+        d.kind = gain ? (uint32_t)RC_DK_BAND : e->cfg.device_kernel;
+        d.gain_in = e->cfg.dk_gain;
+        d.gain_out = gain ? e->cfg.dk_gain : e->cfg.dk_gain_outside;
+        d.lo_bin = gain ? 0u : e->cfg.dk_lo_bin;
+        d.hi_bin = gain ? N : e->cfg.dk_hi_bin;
+        d.shift = e->cfg.dk_shift_bins;
+        d.hops_total = 1;
+        RC_HIP(rc::launch_dev_kernel(d, e->stream));
+        p.spec = d.out;
     }
     if ((rc = single_hop_resynth(e, p))) return rc;
     RC_HIP(hipMemcpyAsync(out, e->d_ybuf.p, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, e->stream));

@@ -146,4 +146,18 @@ hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only = false)
 hipError_t launch_big(int stage, const BigParams &p, hipStream_t s, HopMode mode = MODE_FUSED);
 hipError_t launch_big_cr(const BigOlaParams &p, hipStream_t s);
 
+// Curated on-GPU frequency kernels (rc_config::device_kernel, RC_DK_BAND / RC_DK_SHIFT): Y = K(X) on the
+// natural-order N-bin spectra [hops_total][N] between the forward and the resynthesis kernels.
+struct DevKernelParams {
+    const float2 *in;    // [hops_total][N]
+    float2 *out;         // may equal `in` for BAND; must differ for SHIFT
+    uint32_t log2n;
+    uint32_t kind;       // 2 = band, 3 = shift (values of RC_DK_*)
+    float gain_in, gain_out;
+    uint32_t lo_bin, hi_bin;
+    int32_t shift;
+    uint64_t hops_total;
+};
+hipError_t launch_dev_kernel(const DevKernelParams &p, hipStream_t s);
+
 }  // namespace rc

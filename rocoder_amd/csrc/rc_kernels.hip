@@ -2939,6 +2939,44 @@ hipError_t launch_big_cr(const BigOlaParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Y = K(X) of the curated device kernels, one thread per bin (natural order, all N bins).
+__global__ __launch_bounds__(256) void dev_kernel(const DevKernelParams p) {
+    const uint32_t N = 1u << p.log2n, M = N / 2;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t hop = blockIdx.y;
+    if (j >= N) return;
+    const float2 *x = p.in + hop * N;
+    float2 y;
+    if (p.kind == 2) {  // band mask, symmetric in frequency
+        const uint32_t f = j <= M ? j : N - j;
+        const float g = (f >= p.lo_bin && f <= p.hi_bin) ? p.gain_in : p.gain_out;
+        y = make_float2(x[j].x * g, x[j].y * g);
+    } else {            // shift by whole bins: Y[f] = X[f - s] on 0..M, Y[N - f] = conj(Y[f])
+        const uint32_t f = j <= M ? j : N - j;
+        const int64_t src = (int64_t)f - p.shift;
+        y = make_float2(0.f, 0.f);
+        if (src >= 0 && src <= (int64_t)M) {
+            y = x[src];
+            if (j > M) y.y = -y.y;
+        }
+    }
+    p.out[hop * N + j] = y;
+}
+hipError_t launch_dev_kernel(const DevKernelParams &p, hipStream_t s) {
+    const uint32_t N = 1u << p.log2n;
+    const uint64_t per_launch = 32768;  // grid.y limit
+    for (uint64_t h0 = 0; h0 < p.hops_total; h0 += per_launch) {
+        DevKernelParams q = p;
+        q.in = p.in + h0 * N;
+        q.out = p.out + h0 * N;
+        q.hops_total = p.hops_total - h0 < per_launch ? p.hops_total - h0 : per_launch;
+        hipLaunchKernelGGL(dev_kernel, dim3((N + 255) / 256, (unsigned)q.hops_total), dim3(256), 0, s, q);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only) {
     const dim3 grid((unsigned)p.hop_count, p.n_channels), block(256);
     if (!tail_only) {

@@ -68,7 +68,9 @@ def load_kernel_library(path: str):
 
 def make_config(window_len=16384, factor=1.0, amplitude=1.0, pitch_multiple=1, sample_rate=44100,
                 channels=1, buffer_secs=1.0, seed=0, device=0, window=None, kernel=None,
-                kernel_time_ms=0, max_batch_hops=0):
+                kernel_time_ms=0, max_batch_hops=0, kernel_threads=0, device_kernel=None):
+    """device_kernel: None, ("gain", g), ("band", lo_bin, hi_bin, gain_inside, gain_outside) or
+    ("shift", bins) - the curated on-GPU frequency kernels of include/rocoder_hip.h (RC_DK_*)."""
     cfg = rc_config()
     cfg.struct_size = C.sizeof(rc_config)
     cfg.window_len = int(window_len)
@@ -92,6 +94,19 @@ def make_config(window_len=16384, factor=1.0, amplitude=1.0, pitch_multiple=1, s
     cfg.kernel = k
     keep.append(k)
     cfg.kernel_time_ms = int(kernel_time_ms)
+    cfg.kernel_threads = int(kernel_threads)
+    if device_kernel is not None:
+        kind = device_kernel[0]
+        if kind == "gain":
+            cfg.device_kernel, cfg.dk_gain = _lib.RC_DK_GAIN, float(device_kernel[1])
+        elif kind == "band":
+            cfg.device_kernel = _lib.RC_DK_BAND
+            cfg.dk_lo_bin, cfg.dk_hi_bin = int(device_kernel[1]), int(device_kernel[2])
+            cfg.dk_gain, cfg.dk_gain_outside = float(device_kernel[3]), float(device_kernel[4])
+        elif kind == "shift":
+            cfg.device_kernel, cfg.dk_shift_bins = _lib.RC_DK_SHIFT, int(device_kernel[1])
+        else:
+            raise ValueError(f"unknown device kernel {kind!r}")
     return cfg, keep
 
 
@@ -414,12 +429,14 @@ class StretcherProcessor:
 
 
 def stretch(channels_in, window_len=16384, factor=1.0, amplitude=1.0, pitch_multiple=1, seed=0,
-            sample_rate=44100, kernel=None, device=0, kernel_time_ms=0) -> np.ndarray:
+            sample_rate=44100, kernel=None, device=0, kernel_time_ms=0, kernel_threads=0,
+            device_kernel=None) -> np.ndarray:
     """Offline `-o` run (src/main.rs:124-160 minus file I/O): host [C, L] -> host [C, n_out]."""
     x = np.ascontiguousarray(np.atleast_2d(channels_in), dtype=np.float32)
     with Engine(window_len=window_len, factor=factor, amplitude=amplitude,
                 pitch_multiple=pitch_multiple, sample_rate=sample_rate, channels=x.shape[0],
-                seed=seed, device=device, kernel=kernel, kernel_time_ms=kernel_time_ms) as e:
+                seed=seed, device=device, kernel=kernel, kernel_time_ms=kernel_time_ms,
+                kernel_threads=kernel_threads, device_kernel=device_kernel) as e:
         return e.stretch_host(x)
 
 

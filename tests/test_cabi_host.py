@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/rocoder_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
-    assert L.rc_abi_version() == 1
+    assert L.rc_abi_version() == 2
 
 
 @pytest.mark.parametrize("N,f,p,a", [(16384, 1.0, 1, 1.0), (16384, 8.0, 1, 1.0), (16384, 8.0, 3, 1.0),

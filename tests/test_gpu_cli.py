@@ -102,3 +102,43 @@ def test_cli_broken_kernel_source_falls_back_to_noop(tmp_path):
     assert "Failed to compile library" in r.stderr  # src/hotswapper.rs:39
     _, got = read_wav_f32(out)
     check(got, oc.stretch_offline(dec, 1024, 2.0, 1.0, 1, seed=9))
+
+
+SLOW_GAIN_C = r"""
+#include <stddef.h>
+#include <stdint.h>
+#include <unistd.h>
+int apply(uint64_t time_ms, const float *in, float *out, size_t n, void *user) {
+    (void)time_ms; (void)user;
+    usleep(%d);
+    for (size_t i = 0; i < 2 * n; ++i) out[i] = in[i] * %sf;
+    return 0;
+}
+"""
+
+
+def test_cli_kernel_source_is_reloaded_while_running(tmp_path):
+    """src/hotswapper.rs:19-30 + src/fft.rs:78-85: the kernel source is polled every 100 ms; an edit made
+    while the stretch runs is compiled and takes over for the hops that follow ("Got new kernel" a second
+    time, output gain changes from 1 to 3 somewhere inside the file)."""
+    import time
+
+    x = onp.synth_input(0, 60000)[None]
+    wav, out, ksrc = str(tmp_path / "in.wav"), str(tmp_path / "out.wav"), str(tmp_path / "kernel.c")
+    dec = write_wav(wav, x, 44100, "f32")
+    open(ksrc, "w").write(SLOW_GAIN_C % (3000, "1.0"))  # ~470 hops x 3 ms: the run lasts > 1 s
+    p = subprocess.Popen([CLI, "-i", wav, "-o", out, "-w", "1024", "-f", "4", "--freq-kernel", ksrc, "--seed", "9"],
+                         stderr=subprocess.PIPE, text=True)
+    time.sleep(0.5)
+    open(ksrc, "w").write(SLOW_GAIN_C % (0, "3.0"))
+    _, err = p.communicate(timeout=120)
+    assert p.returncode == 0, err
+    assert err.count("Got new kernel") == 2, err
+    _, got = read_wav_f32(out)
+    ref = oc.stretch_offline(dec, 1024, 4.0, 1.0, 1, seed=9)  # gain 1
+    assert got.shape == ref.shape
+    n = ref.shape[1]
+    head, tail = slice(0, n // 20), slice(n - n // 10, n)
+    g_head = rms(got[0, head]) / rms(ref[0, head])
+    g_tail = rms(got[0, tail]) / rms(ref[0, tail])
+    assert abs(g_head - 1.0) < 1e-3 and abs(g_tail - 3.0) < 3e-3, (g_head, g_tail)

@@ -272,6 +272,72 @@ def test_refft_seam_on_large_window():  # src/fft.rs:42-74 at window_len 32768
     assert_parity(y, yo, "resynth 32768")
 
 
+def _np_band(lo, hi, gi, go):
+    def k(t, spec):
+        n = spec.size
+        f = np.minimum(np.arange(n), n - np.arange(n))
+        g = np.where((f >= lo) & (f <= hi), np.float32(gi), np.float32(go)).astype(np.float32)
+        return spec * g
+    return k
+
+
+def _np_shift(s):
+    def k(t, spec):
+        n = spec.size
+        m = n // 2
+        out = np.zeros(n, np.complex64)
+        f = np.arange(m + 1)
+        src = f - s
+        ok = (src >= 0) & (src <= m)
+        out[f[ok]] = spec[src[ok]]
+        j = np.arange(m + 1, n)
+        out[j] = np.conj(out[n - j])
+        return out
+    return k
+
+
+@pytest.mark.parametrize("N,f,p", [(2048, 4.0, 1), (16384, 8.0, 1), (4096, 2.0, 2), (32768, 8.0, 1)])
+def test_device_side_curated_kernels_match_host_kernels(N, f, p):
+    """SURVEY §8 f2: gain / band mask / spectral shift run on the GPU (rc_config::device_kernel): the
+    spectrum never crosses PCIe. Each must equal the oracle run with the same function as a host kernel."""
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, 5 * N + 333) for c in range(2)])
+    base = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=17)
+    # gain: rides on the amplitude factor of the fused kernels - a power of two is exact
+    g2 = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=17, device_kernel=("gain", 2.0))
+    assert np.array_equal(g2, 2.0 * base)
+    g15 = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=17, device_kernel=("gain", -1.5))
+    assert_parity(g15, oc.stretch_offline(x, N, f, 1.0, p, seed=17, kernel=_kernel_for(-1.5)), "gain -1.5")
+    lo, hi = N // 64, N // 8
+    band = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=17, device_kernel=("band", lo, hi, 1.25, 0.1))
+    assert_parity(band, oc.stretch_offline(x, N, f, 1.0, p, seed=17, kernel=_np_band(lo, hi, 1.25, 0.1)), "band")
+    for sh in (37, -11):
+        got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=17, device_kernel=("shift", sh))
+        assert_parity(got, oc.stretch_offline(x, N, f, 1.0, p, seed=17, kernel=_np_shift(sh)), f"shift {sh}")
+
+
+def test_device_kernel_and_host_kernel_are_exclusive():
+    ra = _engine_mod()
+    from rocoder_amd import _lib
+
+    with pytest.raises(_lib.RocoderError) as ei:
+        ra.stretch(np.zeros((1, 5000), np.float32), window_len=1024, kernel=_kernel_for(2.0),
+                   device_kernel=("gain", 2.0))
+    assert ei.value.code == _lib.RC_EINVAL
+
+
+def test_kernel_threads_give_the_single_thread_result(tmp_path):
+    """rc_config::kernel_threads: channels dealt to host threads (per-channel hop order kept). For a
+    re-entrant kernel the result is that of the reference's single DSP thread."""
+    ra = _engine_mod()
+    k = _compiled_gain2(tmp_path)
+    x = np.stack([onp.synth_input(c, 200_000) for c in range(4)])
+    one = ra.stretch(x, window_len=4096, factor=4.0, seed=3, kernel=k)
+    four = ra.stretch(x, window_len=4096, factor=4.0, seed=3, kernel=k, kernel_threads=4)
+    three = ra.stretch(x, window_len=4096, factor=4.0, seed=3, kernel=k, kernel_threads=3)
+    assert np.array_equal(one, four) and np.array_equal(one, three)
+
+
 def test_panicking_kernel_falls_back_to_identity():  # src/fft.rs:100-106
     ra = _engine_mod()
 
@@ -306,6 +372,38 @@ def test_kernel_call_order_and_time():
     assert len(calls) == len(ocalls)
     assert all(c[0] == 4242 and c[1] == 512 for c in calls)
     assert np.allclose([c[2] for c in calls], ocalls, rtol=1e-4)
+
+
+def test_streaming_kernel_call_order_is_the_processors():
+    """A stateful apply() behind the streaming seam: the StretcherProcessor asks channel 0 for a window,
+    then channel 1, ... (src/stretcher_processor.rs:63-70) and apply() must see the hops in exactly that
+    order - no look-ahead past the window that was asked for."""
+    ra = _engine_mod()
+    calls = []
+
+    def k(t, spec):
+        calls.append(round(float(np.abs(spec).sum()), 1))
+        return spec
+
+    x = np.stack([onp.synth_input(c, 9000) for c in range(2)])
+    w = oc.hanning(512)
+    spec = ra.AudioSpec(2, 44100)
+    eng = ra.Engine(window_len=512, window=w, factor=2.0, sample_rate=44100, channels=2, seed=1, kernel=k,
+                    kernel_time_ms=1)
+    sts = []
+    for c in range(2):
+        q: "queue.Queue" = queue.Queue()
+        q.put(x[c])
+        q.put(None)
+        sts.append(ra.Stretcher(spec, q, 2.0, 1.0, 1, w, seed=1, channel_index=c, _engine=eng))
+    proc, bus = ra.StretcherProcessor.new(sts, int(x.shape[1] * 2.0))
+    proc.start()
+    bus.into_audio()
+    proc.join(timeout=60)
+    ocalls = []
+    oc.stretch_offline(x, 512, 2.0, 1.0, 1, seed=1,
+                       kernel=lambda t, s: (ocalls.append(round(float(np.abs(s).sum()), 1)), s)[1])
+    assert len(calls) == len(ocalls) and np.allclose(calls, ocalls, rtol=1e-4)
 
 
 # ------------------------------------------------------------------ streaming seam
