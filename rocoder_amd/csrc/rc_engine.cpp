@@ -175,6 +175,7 @@ struct rc_engine {
     float *d_hann_rot = nullptr;  // N = 16384 with the default window only (HopParams::hann_rot)
     float2 *d_wtab = nullptr, *d_rtab = nullptr;
     float2 *d_t1 = nullptr;  // large windows only: exp(-2 pi i j / (N/2)), j <= N/8
+    float2 *d_wtab_m = nullptr;  // large windows, fused kernel: exp(-2 pi i k / (N/2)), k <= N/64
     uint64_t seed_mixed = 0;
     int n_cu = 256;
     std::vector<Channel> ch;
@@ -618,6 +619,35 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         }
         return RC_OK;
     }
+#ifndef RC_BIG4
+#define RC_BIG4 1
+#endif
+    if (RC_BIG4 && e->log2n > 14 && !e->cfg.kernel && !devk && e->cfg.pitch_multiple >= 1 &&
+        !(e->diag_flags & rc::RC_DIAG_PREV_KERNEL)) {
+        // fused large-window kernel: one workgroup (512 threads, ~150 KB of LDS: one per CU) per run of hops,
+        // about three rounds of workgroups per launch; each run recomputes the hop before it for its tail
+        p.hop_first = hop_first;
+        p.hop_count = hop_count;
+        p.wtab = e->d_wtab_m;
+        uint64_t r = std::max<uint64_t>(1, (uint64_t)e->n_cu * 3 / n_channels);
+        r = std::max<uint64_t>(1, std::min<uint64_t>(r, (uint64_t)hop_count / 8));
+        const uint64_t len = ((uint64_t)hop_count + r - 1) / r;
+        p.run_len = (uint32_t)len;
+        p.runs_per_channel = (uint32_t)(((uint64_t)hop_count + len - 1) / len);
+        if (e->log2n == 16) {  // the carried tail goes through a per-workgroup scratch (rc_kernels.hip)
+            if (int rcs = e->d_ybuf.reserve((size_t)p.runs_per_channel * n_channels * H * sizeof(float))) return rcs;
+            p.ybuf = (float *)e->d_ybuf.p;
+        }
+        if (timed) RC_HIP(hipEventRecord(e->ev0[e->timed_calls % rc_engine::kRing], s));
+        RC_HIP(rc::launch_big4(e->log2n, p, s));
+        if (timed) {
+            RC_HIP(hipEventRecord(e->ev1[e->timed_calls % rc_engine::kRing], s));
+            e->timed_calls++;
+            e->stats_hops = (uint64_t)hop_count * n_channels;
+            e->stats_launches = 1;
+        }
+        return RC_OK;
+    }
     // ---- unfused pipeline: y_k for a chunk of hops lands in HBM scratch, then a gather-form
     // overlap-add kernel writes the output. Used for
     //   * a user frequency kernel: forward -> host apply() per hop -> resynth. apply() may be
@@ -983,6 +1013,13 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
     if (big) {
         RC_HIP_C(hipMalloc((void **)&e->d_t1, t1.size() * sizeof(float2)));
         RC_HIP_C(hipMemcpy(e->d_t1, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice));
+        std::vector<float2> wm(N / 64 + 1);  // big4_kernel: W_M^k for k <= RES/2, RES = N/32
+        for (uint32_t k = 0; k < wm.size(); ++k) {
+            const double a = -2.0 * M_PI * (double)k / (double)M;
+            wm[k] = make_float2((float)cos(a), (float)sin(a));
+        }
+        RC_HIP_C(hipMalloc((void **)&e->d_wtab_m, wm.size() * sizeof(float2)));
+        RC_HIP_C(hipMemcpy(e->d_wtab_m, wm.data(), wm.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
 #undef RC_HIP_C
     *out = e;
@@ -1001,6 +1038,7 @@ void rc_engine_destroy(rc_engine *e) {
     if (e->d_wtab) (void)hipFree(e->d_wtab);
     if (e->d_rtab) (void)hipFree(e->d_rtab);
     if (e->d_t1) (void)hipFree(e->d_t1);
+    if (e->d_wtab_m) (void)hipFree(e->d_wtab_m);
     e->d_in.release();
     e->d_out.release();
     e->d_spec.release();

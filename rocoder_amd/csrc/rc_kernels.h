@@ -145,6 +145,11 @@ hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only = false)
 // mode selects stage B's variant (user-kernel path: MODE_FORWARD, host apply(), MODE_RESYNTH)
 hipError_t launch_big(int stage, const BigParams &p, hipStream_t s, HopMode mode = MODE_FUSED);
 hipError_t launch_big_cr(const BigOlaParams &p, hipStream_t s);
+// Fused large-window kernel (log2n 15 / 16, pitch >= 1, no spectrum kernel): HopParams with
+// wtab = exp(-2 pi i k / M) [>= RES/2 + 1], rtab = exp(-2 pi i j / N) [>= RES/2 + 1], RES = N / 32, and for
+// log2n 16 ybuf = tail scratch of runs * n_channels * N/2 floats. One workgroup walks one run and
+// recomputes the hop before it for its tail.
+hipError_t launch_big4(int log2n, const HopParams &p, hipStream_t s);
 
 // Curated on-GPU frequency kernels (rc_config::device_kernel, RC_DK_BAND / RC_DK_SHIFT): Y = K(X) on the
 // natural-order N-bin spectra [hops_total][N] between the forward and the resynthesis kernels.

@@ -1,6 +1,9 @@
-"""BASELINE C5 on one GPU (8 channels, window 65536, factor 32): wall time per job; run under
-rocprofv3 --kernel-trace --stats for the per-kernel split of the large-window pipeline."""
+"""BASELINE C5 on one GPU (8 channels, window 65536, factor 32, L = 5 292 000 per channel) and the same job at
+window 32768: pre-heated, median of the per-launch event times the engine records. ROCODER_DIAG=2 runs the
+previous three-kernel pipeline instead of the fused big4_kernel."""
+import json
 import os
+import statistics
 import sys
 import time
 
@@ -10,18 +13,29 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rocoder_amd  # noqa: E402
 
 dev = torch.device("cuda", 0)
+res = {"diag": os.environ.get("ROCODER_DIAG", "0")}
 x8 = (torch.rand((8, 5_292_000), device=dev) - 0.5)
-e = rocoder_amd.Engine(window_len=65536, factor=32.0, channels=8, seed=1)
-out = torch.empty((8, e.output_len(x8.shape[1])), device=dev)
 stream = torch.cuda.Stream(dev)
 with torch.cuda.stream(stream):
-    e.stretch_tensor(x8, out=out)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
+    for N, f in ((65536, 32.0), (32768, 32.0)):
+        e = rocoder_amd.Engine(window_len=N, factor=f, channels=8, seed=1)
+        out = torch.empty((8, e.output_len(x8.shape[1])), device=dev)
         e.stretch_tensor(x8, out=out)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 3
-hops = out.shape[1] // 32768 * 8
-print(f"C5 one GPU: {dt * 1e3:.2f} ms per job, {hops} hops, {hops / dt / 1e6:.2f} M hops/s, "
-      f"{out.numel() / dt / 1e9:.1f} Gsamples/s")
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 1.0:
+            for _ in range(4):
+                e.stretch_tensor(x8, out=out)
+            stream.synchronize()
+        for _ in range(10):
+            e.stretch_tensor(x8, out=out)
+        stream.synchronize()
+        ms = e.kernel_times(10)
+        _, hops, launches = e.last_kernel_stats()
+        med = statistics.median(ms)
+        res[f"N{N}"] = dict(ms_median=round(med, 3), ms_min=round(min(ms), 3), hops=hops, launches=launches,
+                            hops_per_s=round(hops / med * 1e3), out_gsamples_s=round(out.numel() / med / 1e6, 1),
+                            algo_read_GBs=round(hops * 4.0 * N / med / 1e6, 1),
+                            frac_hbm=round(hops * 4.0 * N / med / 1e6 / 8000.0, 4))
+        e.close()
+        del out
+print(json.dumps(res))
