@@ -172,7 +172,7 @@ struct rc_engine {
     uint64_t stats_hops = 0;
     uint32_t stats_launches = 0;
     float *d_window = nullptr, *d_env = nullptr;
-    float *d_hann_rot = nullptr;  // N = 16384 with the default window only (HopParams::hann_rot)
+    float *d_hann_rot = nullptr;  // N >= 16384 with the default window only (HopParams::hann_rot)
     float2 *d_wtab = nullptr, *d_rtab = nullptr;
     float2 *d_t1 = nullptr;  // large windows only: exp(-2 pi i j / (N/2)), j <= N/8
     float2 *d_wtab_m = nullptr;  // large windows, fused kernel: exp(-2 pi i k / (N/2)), k <= N/64
@@ -235,7 +235,7 @@ void plan_runs(const rc_engine *e, uint32_t n_channels, int64_t hop_count, uint3
     uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(lds_cap / std::max<size_t>(lds, 1), 2048 / threads));
     wg_per_cu = std::min<uint32_t>(wg_per_cu, 8);
     uint32_t rounds = RC_ROUNDS;
-    if (const int fixed = rc::hop_workgroups_per_cu(e->log2n, e->d_hann_rot != nullptr)) {
+    if (const int fixed = rc::hop_workgroups_per_cu(e->log2n, e->d_hann_rot != nullptr)) {  // (N = 16384 only)
         wg_per_cu = (uint32_t)fixed;
         rounds = 2 * RC_ROUNDS;  // measured: 4 rounds of 768 workgroups beat 2 (tail balance) and 6
     }
@@ -945,15 +945,18 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
         default_window = memcmp(d.data(), w.data(), N * sizeof(float)) == 0;
     }
     std::vector<float> hann_rot;
-    if (default_window && log2n == 14) {
-        hann_rot.resize(2 * 256 * 4);
+    if (default_window && log2n >= 14) {
+        // thread t of the fused kernels touches samples 2 T q + 2 t + e: {cos, sin}(2 pi (2 t + e) / (len - 1)) for
+        // the window (len = N) and the envelope (len = N / 2); T = 256 threads at N = 16384, 512 above
+        const int threads = log2n == 14 ? 256 : 512;
+        hann_rot.resize((size_t)2 * threads * 4);
         for (int part = 0; part < 2; ++part) {
             const double len1 = (double)((part ? H : N) - 1);
-            for (int t = 0; t < 256; ++t)
+            for (int t = 0; t < threads; ++t)
                 for (int b = 0; b < 2; ++b) {
                     const double beta = 2.0 * M_PI * (double)(2 * t + b) / len1;
-                    hann_rot[(part * 256 + t) * 4 + 2 * b] = (float)cos(beta);
-                    hann_rot[(part * 256 + t) * 4 + 2 * b + 1] = (float)sin(beta);
+                    hann_rot[((size_t)part * threads + t) * 4 + 2 * b] = (float)cos(beta);
+                    hann_rot[((size_t)part * threads + t) * 4 + 2 * b + 1] = (float)sin(beta);
                 }
         }
     }

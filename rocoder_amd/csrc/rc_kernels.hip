@@ -2792,6 +2792,24 @@ constexpr W64Tab make_w64() {  // exp(-2 pi i c / 64), c < 32
     return t;
 }
 __device__ constexpr W64Tab W64 = make_w64();
+// default-window fast path of big4_kernel (as HANN_W14 for hop4): value(i) = base + c[q] cos(beta) + s[q] sin(beta)
+// for sample i = 1024 q + 2 t + e, beta = 2 pi (2 t + e) / (len - 1)
+struct HannK64 {
+    float c[64], s[64];
+};
+constexpr HannK64 make_hann_k64(double amp, int len, int count) {
+    HannK64 k{};
+    for (int q = 0; q < 64; ++q) {
+        const double a = q < count ? 2.0 * CX_PI * 1024.0 * q / (double)(len - 1) : 0.0;
+        k.c[q] = (float)(-amp * cx_cos(a));
+        k.s[q] = (float)(amp * cx_sin(a));
+    }
+    return k;
+}
+__device__ constexpr HannK64 HANN_W15 = make_hann_k64(0.5, 32768, 32);
+__device__ constexpr HannK64 HANN_E15 = make_hann_k64(HANN_ENV_AMP, 16384, 16);
+__device__ constexpr HannK64 HANN_W16 = make_hann_k64(0.5, 65536, 64);
+__device__ constexpr HannK64 HANN_E16 = make_hann_k64(HANN_ENV_AMP, 32768, 32);
 
 // dit_stages for up to 64 registers: 64th-root constants, otherwise the same arithmetic
 template <int NREG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L>
@@ -2853,12 +2871,18 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
     }
 }
 
+#ifndef RC_B4_LB
+#define RC_B4_LB 32
+#endif
+#ifndef RC_B4_TPRE
+#define RC_B4_TPRE 0
+#endif
 constexpr int BIG4_T = 512;
 constexpr int BIG4_XBUF = 16400;  // exchange buffer, float2 slots (16384 + the 15 of the E1 / E3 index map)
 // tables behind the buffer: W_M^r [TA], W_N^r [TR] for r <= RES/2, thread 0's second twiddle base
 constexpr int big4_lds_float2(int R) { return BIG4_XBUF + 2 * (16 * R + 1) + 8; }
 
-template <int R, bool PITCH1>
+template <int R, bool PITCH1, bool HANN>
 __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
     constexpr int b = clog2(R), m = b + 9, LOG2N = m + 1, M = 1 << m, H = M, T = BIG4_T;
     constexpr int RES = 1 << (b + 5), G = R / 32, NS = R / 16, PH = R / 2;
@@ -2910,18 +2934,39 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         {   // register brev_b(q) := z[q * T + t] * window
             GF src = hop_src(p, xc, xt, k);
             GF win = per_hop(p.window);
+            v2f cbW = {0.f, 0.f}, sbW = cbW;
+            if constexpr (HANN) {  // {cos, sin}(beta) of this thread's two samples, from the engine's table
+                GV2 hr = (GV2)per_hop(p.hann_rot) + 2 * tid;
+                const float2 a0 = ldg2(hr), a1 = ldg2(hr + 1);
+                cbW = v2f{a0.x, a1.x};
+                sbW = v2f{a0.y, a1.y};
+            }
+            const HannK64 &HW = R == 32 ? HANN_W15 : HANN_W16;
+            // every load of the hop in flight at once when the window is computed (one memory latency per
+            // hop); batches of 16 when the window comes from its table too (register budget)
+            constexpr int LB = HANN ? (R > 32 ? RC_B4_LB : R) : 16;
 #pragma unroll
-            for (int q0 = 0; q0 < R; q0 += 16) {  // loads in batches of 16 (register budget)
-                float xr0[16], xr1[16], wr0[16], wr1[16];
+            for (int q0 = 0; q0 < R; q0 += LB) {
+                float xr0[LB], xr1[LB], wr0[HANN ? 1 : LB], wr1[HANN ? 1 : LB];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
+                for (int q = 0; q < LB; ++q) {
                     xr0[q] = (src + 2 * T * (q0 + q))[lane2];
                     xr1[q] = (src + 2 * T * (q0 + q))[lane2 + 1];
-                    wr0[q] = (win + 2 * T * (q0 + q))[lane2];
-                    wr1[q] = (win + 2 * T * (q0 + q))[lane2 + 1];
+                    if constexpr (!HANN) {
+                        wr0[q] = (win + 2 * T * (q0 + q))[lane2];
+                        wr1[q] = (win + 2 * T * (q0 + q))[lane2 + 1];
+                    }
                 }
 #pragma unroll
-                for (int q = 0; q < 16; ++q) v[brev_c(q0 + q, b)] = v2f{xr0[q], xr1[q]} * v2f{wr0[q], wr1[q]};
+                for (int q = 0; q < LB; ++q) {
+                    v2f wq;
+                    if constexpr (HANN)
+                        wq = __builtin_elementwise_fma(v2f{HW.s[q0 + q], HW.s[q0 + q]}, sbW,
+                             __builtin_elementwise_fma(v2f{HW.c[q0 + q], HW.c[q0 + q]}, cbW, v2f{0.5f, 0.5f}));
+                    else
+                        wq = v2f{wr0[q], wr1[q]};
+                    v[brev_c(q0 + q, b)] = v2f{xr0[q], xr1[q]} * wq;
+                }
             }
             dit_g<R, 0, b - 1, 0, false, false>(v);
         }
@@ -3112,31 +3157,63 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 for (int q = 0; q < 32; ++q) y[q + 32 * g] = to_v(lds[tid + (q << 9)]);
             }
         }
+        // R = 64: the carried tail comes back from the scratch; requested here, behind the last exchange, so that
+        // its latency hides under I3 (v is dead: there are registers for it)
+        constexpr bool TPRE = TAIL_GLOBAL && RC_B4_TPRE;
+        v2f tpre[TPRE ? PH : 1];
+        if constexpr (TPRE) {
+#pragma unroll
+            for (int q = 0; q < PH; ++q) tpre[q] = to_v(ldg2((GV2)tsc + tid + T * q));
+        }
         dit_g<R, 9, m - 1, 9, true, true>(y, to_v(lds[T_A + tid]));
         // ---- epilogue: synthesis window, overlap-add, store (tail in registers or in the scratch)
         {
             GF win = per_hop(p.window);
             GF esrc = per_hop(p.env);
+            v2f cbW = {0.f, 0.f}, sbW = cbW, cbE = cbW, sbE = cbW;
+            if constexpr (HANN) {
+                GV2 hr = (GV2)per_hop(p.hann_rot) + 2 * tid;
+                const float2 a0 = ldg2(hr), a1 = ldg2(hr + 1), e0r = ldg2(hr + 2 * T), e1r = ldg2(hr + 2 * T + 1);
+                cbW = v2f{a0.x, a1.x};
+                sbW = v2f{a0.y, a1.y};
+                cbE = v2f{e0r.x, e1r.x};
+                sbE = v2f{e0r.y, e1r.y};
+            }
+            const HannK64 &HW = R == 32 ? HANN_W15 : HANN_W16;
+            const HannK64 &HE = R == 32 ? HANN_E15 : HANN_E16;
+            const v2f hf = {0.5f, 0.5f};
             const int64_t g0 = k * (int64_t)H;
             GFW dst = outc + (g0 / (int64_t)pitch - p.out_origin);
             const uint32_t kr = (uint32_t)(g0 % pitch);
+            constexpr int EB = R > 32 ? 4 : 8;  // batch of table loads in flight (register budget)
 #pragma unroll
-            for (int q0 = 0; q0 < PH; q0 += 8) {
-                float wr0[8], wr1[8], wt0[8], wt1[8], e0[8], e1[8];
-                v2f tq[8];
+            for (int q0 = 0; q0 < PH; q0 += EB) {
+                float wr0[EB], wr1[EB], wt0[EB], wt1[EB], e0[EB], e1[EB];
+                v2f tq[EB];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    wr0[q] = (win + 2 * T * (q0 + q))[lane2];
-                    wr1[q] = (win + 2 * T * (q0 + q))[lane2 + 1];
-                    wt0[q] = (win + 2 * T * (q0 + q + PH))[lane2];
-                    wt1[q] = (win + 2 * T * (q0 + q + PH))[lane2 + 1];
-                    e0[q] = (esrc + 2 * T * (q0 + q))[lane2];
-                    e1[q] = (esrc + 2 * T * (q0 + q))[lane2 + 1];
-                    if constexpr (TAIL_GLOBAL) tq[q] = to_v(ldg2((GV2)tsc + tid + T * (q0 + q)));
+                for (int q = 0; q < EB; ++q) {
+                    if constexpr (!HANN) {
+                        wr0[q] = (win + 2 * T * (q0 + q))[lane2];
+                        wr1[q] = (win + 2 * T * (q0 + q))[lane2 + 1];
+                        wt0[q] = (win + 2 * T * (q0 + q + PH))[lane2];
+                        wt1[q] = (win + 2 * T * (q0 + q + PH))[lane2 + 1];
+                        e0[q] = (esrc + 2 * T * (q0 + q))[lane2];
+                        e1[q] = (esrc + 2 * T * (q0 + q))[lane2 + 1];
+                    } else {
+                        const v2f wh = __builtin_elementwise_fma(v2f{HW.s[q0 + q], HW.s[q0 + q]}, sbW,
+                                       __builtin_elementwise_fma(v2f{HW.c[q0 + q], HW.c[q0 + q]}, cbW, hf));
+                        const v2f wt = __builtin_elementwise_fma(v2f{HW.s[q0 + q + PH], HW.s[q0 + q + PH]}, sbW,
+                                       __builtin_elementwise_fma(v2f{HW.c[q0 + q + PH], HW.c[q0 + q + PH]}, cbW, hf));
+                        const v2f ev = __builtin_elementwise_fma(v2f{HE.s[q0 + q], HE.s[q0 + q]}, sbE,
+                                       __builtin_elementwise_fma(v2f{HE.c[q0 + q], HE.c[q0 + q]}, cbE, hf));
+                        wr0[q] = wh.x, wr1[q] = wh.y, wt0[q] = wt.x, wt1[q] = wt.y, e0[q] = ev.x, e1[q] = ev.y;
+                    }
+                    if constexpr (TPRE) tq[q] = tpre[q0 + q];
+                    else if constexpr (TAIL_GLOBAL) tq[q] = to_v(ldg2((GV2)tsc + tid + T * (q0 + q)));
                     else tq[q] = tail[q0 + q];
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < EB; ++q) {
                     const v2f head = y[q0 + q] * v2f{wr0[q], wr1[q]};
                     const v2f nt = y[q0 + q + PH] * v2f{wt0[q], wt1[q]};
                     if (k >= k_begin) {
@@ -3371,20 +3448,21 @@ hipError_t launch_dev_kernel(const DevKernelParams &p, hipStream_t s) {
     return hipSuccess;
 }
 
-hipError_t launch_big4(int log2n, const HopParams &p, hipStream_t s) {
+template <int R>
+hipError_t launch_big4_r(const HopParams &p, hipStream_t s) {
     const dim3 grid(p.runs_per_channel * p.n_channels), block(BIG4_T);
-    if (log2n == 15) {
-        const size_t lds = sizeof(float2) * (size_t)big4_lds_float2(32);
-        if (p.pitch == 1) hipLaunchKernelGGL((big4_kernel<32, true>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((big4_kernel<32, false>), grid, block, lds, s, p);
-    } else if (log2n == 16) {
-        const size_t lds = sizeof(float2) * (size_t)big4_lds_float2(64);
-        if (p.pitch == 1) hipLaunchKernelGGL((big4_kernel<64, true>), grid, block, lds, s, p);
-        else hipLaunchKernelGGL((big4_kernel<64, false>), grid, block, lds, s, p);
-    } else {
-        return hipErrorInvalidValue;
-    }
+    const size_t lds = sizeof(float2) * (size_t)big4_lds_float2(R);
+    const bool hann = p.hann_rot != nullptr;
+    if (p.pitch == 1 && hann) hipLaunchKernelGGL((big4_kernel<R, true, true>), grid, block, lds, s, p);
+    else if (p.pitch == 1) hipLaunchKernelGGL((big4_kernel<R, true, false>), grid, block, lds, s, p);
+    else if (hann) hipLaunchKernelGGL((big4_kernel<R, false, true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((big4_kernel<R, false, false>), grid, block, lds, s, p);
     return hipGetLastError();
+}
+hipError_t launch_big4(int log2n, const HopParams &p, hipStream_t s) {
+    if (log2n == 15) return launch_big4_r<32>(p, s);
+    if (log2n == 16) return launch_big4_r<64>(p, s);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only) {
