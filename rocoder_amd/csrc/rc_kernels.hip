@@ -1967,6 +1967,15 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
     struct Who {
         int wv, lane, cc, lo4, nib, r, A0;
     };
+    // two of them ARE kept (one VGPR each): the class nibble (a dozen operations) and the own-region base
+    int nib_keep, a0_keep;
+    {
+        const int w_ = tid >> 6, c_ = (tid >> 4) & 3;
+        const int nl3 = c_ & 1, nl2 = c_ >> 1, nl0 = w_ & 1;
+        const int nl1 = nl0 ? ((w_ >> 1) ^ nl2) : (w_ >> 1);
+        nib_keep = (nl3 << 3) | (nl2 << 2) | (nl1 << 1) | nl0;  // member(wv, cc), cc = (l2 << 1 | l3)
+        a0_keep = w_ * REG + (tid & 63);
+    }
     auto who = [&]() {
         int t = tid;
         opaque(t);
@@ -1975,13 +1984,10 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
         w.lane = t & 63;
         w.cc = (t >> 4) & 3;
         w.lo4 = t & 15;
-        // nibble of class wv with index cc = (l2 << 1 | l3): member(wv, cc)
-        const int nl3 = w.cc & 1, nl2 = w.cc >> 1, nl0 = w.wv & 1;
-        const int nl1 = nl0 ? ((w.wv >> 1) ^ nl2) : (w.wv >> 1);
-        w.nib = (nl3 << 3) | (nl2 << 2) | (nl1 << 1) | nl0;
+        w.nib = nib_keep;
         // F2: l4 = nib, uu = lo4.  F3 / I1: residue r = lo4 << 4 | nib (and 512 - r).  I2: l4' = lo4, uu' = brev4(nib)
         w.r = (w.lo4 << 4) | w.nib;
-        w.A0 = w.wv * REG + w.lane;
+        w.A0 = a0_keep;
         return w;
     };
     const int wv = tid >> 6;  // (wave-uniform branches only)

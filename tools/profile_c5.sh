@@ -1,0 +1,36 @@
+#!/bin/bash
+# rocprofv3 kernel stats of BASELINE C5 on one GPU (tools/bench_c5.py: fused big4_kernel) -> gpurun_out/<tag>/
+set -u
+TAG=$1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python3 $GRAFT_REPO_ROOT/tools/bench_c5.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err; cat $OUT/${TAG}_bench.json
+ROCODER_DIAG=2 python3 $GRAFT_REPO_ROOT/tools/bench_c5.py > $OUT/${TAG}_bench_prev_pipeline.json 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tools/bench_c5.py > $OUT/trace.log 2>&1
+find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
+head -6 $OUT/${TAG}_kernel_stats.csv | cut -c1-200
+i=0
+for CNT in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY" \
+           "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $CNT --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/tools/bench_c5.py > $OUT/pass$i.log 2>&1
+done
+python3 - "$OUT" "$TAG" <<'PY'
+import csv, glob, sys, collections
+out, tag = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "big4" in r["Kernel_Name"]:
+            key = "R64 (N=65536)" if "Li64E" in r["Kernel_Name"] or "<64" in r["Kernel_Name"] else "R32 (N=32768)"
+            acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(f"{out}/{tag}_pmc_summary.txt", "w") as g:
+    g.write("# big4_kernel, tools/bench_c5.py (8 ch x 5 292 000, factor 32), mean per launch, separate --pmc passes\n")
+    for key in sorted(acc):
+        g.write(f"## {key}\n")
+        for k in sorted(acc[key]):
+            v = acc[key][k]
+            line = f"{k:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}"
+            print(key, line); g.write(line + "\n")
+PY
