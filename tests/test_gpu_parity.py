@@ -207,6 +207,35 @@ def test_16384_table_window_and_default_window_detection(kind, p):
             assert np.array_equal(e.stretch_host(x[None])[0], got)
 
 
+def test_random_configurations_match_oracle():
+    """A seeded sweep over the parameter space (window 32...65536, factor 0.08...40, pitch -4...4, 1-3 channels,
+    ragged lengths from shorter than a window to a few hundred hops): every kernel family and both ends of the
+    stream logic against the oracle."""
+    ra = _engine_mod()
+    rng = np.random.default_rng(20261003)
+    ran = 0
+    for _ in range(60):
+        N = 1 << int(rng.integers(5, 17))
+        f = float(np.round(np.exp(rng.uniform(np.log(0.08), np.log(40.0))), 3))
+        p = int(rng.choice([-4, -3, -2, 1, 1, 1, 2, 3, 4]))
+        ch = int(rng.integers(1, 4))
+        d = onp.derive(N, f, 1.0, p)
+        if d["step"] < 1:
+            continue
+        hops = int(rng.integers(0, 120 if N <= 16384 else 40))
+        L = int(max(0, hops * d["step"] + rng.integers(-N // 2, N)))
+        if L * max(f, 1.0) * ch > 6e6:  # keep the oracle in seconds
+            continue
+        x = np.stack([onp.synth_input(c, L) for c in range(ch)]) if L else np.zeros((ch, 0), np.float32)
+        got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=ran)
+        ref = oc.stretch_offline(x, N, f, 1.0, p, seed=ran)
+        assert got.shape == ref.shape, (N, f, p, ch, L)
+        if L:
+            assert_parity(got, ref, f"N={N} f={f} p={p} ch={ch} L={L}")
+        ran += 1
+    assert ran >= 35
+
+
 # ------------------------------------------------------------------ user frequency kernel
 def test_gain_kernel_is_exactly_linear():
     # .norm() is linear: the x2.0 kernel config (BASELINE C4) must give 2 * F for the same phases
