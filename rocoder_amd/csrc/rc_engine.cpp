@@ -162,7 +162,9 @@ struct Channel {
 struct rc_engine {
     rc_config cfg{};
     rc_params par{};
-    int log2n = 0;
+    int log2n = 0;     // 0: window_len is not a power of two (gen)
+    bool gen = false;  // O(N^2) DFT path for window lengths that are not a power of two
+    float2 *d_tw_gen = nullptr;  // gen: exp(-2 pi i k / N), k < N
     int device = 0;
     hipStream_t stream = nullptr;
     // event pairs around the kernel launches of the last RC_TIMING_RING offline calls (measurement)
@@ -271,6 +273,8 @@ rc::HopParams base_params(const rc_engine *e) {
     p.step = e->par.sample_step_len;
     p.pitch = (uint32_t)std::max(1, e->cfg.pitch_multiple);
     p.seed_mixed = e->seed_mixed;
+    p.n_generic = e->gen ? e->par.window_len : 0;
+    p.tw_generic = e->d_tw_gen;
     p.err_word = e->d_err;
     p.diag_flags = e->diag_flags;
     // 2^22 polls of ~2 000 cycles each (seconds); the diagnostic build of the protocol gives up at once
@@ -457,6 +461,7 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
         o.hop_first = k0;
         o.hop_count = kc;
         o.log2n = (uint32_t)e->log2n;
+        o.n = N;
         RC_HIP(rc::launch_ola(o, kp.kb, false));
         *launches += 2;
         RC_HIP(hipEventRecord(kp.ev_back[set], kp.kb));
@@ -551,7 +556,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     }
     // RC_DK_BAND / RC_DK_SHIFT act on the spectrum between analysis and resynthesis: unfused, but on the device
     const bool devk = e->cfg.device_kernel == RC_DK_BAND || e->cfg.device_kernel == RC_DK_SHIFT;
-    const bool fused = !e->cfg.kernel && !devk && e->log2n <= 14 && e->cfg.pitch_multiple >= 1;
+    const bool fused = !e->gen && !e->cfg.kernel && !devk && e->log2n <= 14 && e->cfg.pitch_multiple >= 1;
     if (fused) {
         p.hop_first = hop_first;
         p.hop_count = hop_count;
@@ -673,7 +678,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     auto run_chunk = [&](int64_t k0, int64_t kc, bool tail_only) -> int {
         int rcc;
         const size_t spec_floats = (size_t)n_channels * kc * N * 2;
-        if ((!big || devk) && (rcc = e->d_spec.reserve(spec_floats * sizeof(float)))) return rcc;
+        if ((!big || devk || e->gen) && (rcc = e->d_spec.reserve(spec_floats * sizeof(float)))) return rcc;
         if (e->cfg.device_kernel == RC_DK_SHIFT && (rcc = e->d_spec2.reserve(spec_floats * sizeof(float)))) return rcc;
         if ((rcc = e->d_ybuf.reserve((size_t)n_channels * kc * N * sizeof(float)))) return rcc;
         rc::HopParams q = p;
@@ -690,7 +695,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
             b.ysub = (float2 *)e->d_ysub.p;
             b.ybuf = q.ybuf;
             b.spec = q.spec;
-        } else {
+        } else if (!e->gen) {
             plan_runs(e, n_channels, kc, &q.runs_per_channel, &q.run_len);
         }
 #ifndef RC_BIGCR
@@ -724,6 +729,27 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
                                   (size_t)n_channels * H * sizeof(float), hipMemcpyDeviceToDevice, s));
             launches += 3;
             return RC_OK;
+        } else if (e->gen) {
+            // window length that is not a power of two: O(N^2) DFTs, optional device kernel in between
+            RC_HIP(rc::launch_gen(0, q, s));
+            if (devk) {
+                rc::DevKernelParams d{};
+                d.in = (const float2 *)e->d_spec.p;
+                d.out = e->cfg.device_kernel == RC_DK_SHIFT ? (float2 *)e->d_spec2.p : (float2 *)e->d_spec.p;
+                d.n = N;
+                d.kind = e->cfg.device_kernel;
+                d.gain_in = e->cfg.dk_gain;
+                d.gain_out = e->cfg.dk_gain_outside;
+                d.lo_bin = e->cfg.dk_lo_bin;
+                d.hi_bin = e->cfg.dk_hi_bin;
+                d.shift = e->cfg.dk_shift_bins;
+                d.hops_total = (uint64_t)n_channels * (uint64_t)kc;
+                RC_HIP(rc::launch_dev_kernel(d, s));
+                q.spec = d.out;
+            }
+            RC_HIP(rc::launch_gen(1, q, s));
+            RC_HIP(rc::launch_gen(2, q, s));
+            launches += 3;
         } else if (devk) {
             // analysis -> curated device kernel on the N-bin spectra -> resynthesis; nothing leaves the GPU
             if (big) {
@@ -736,6 +762,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
             d.in = (const float2 *)e->d_spec.p;
             d.out = e->cfg.device_kernel == RC_DK_SHIFT ? (float2 *)e->d_spec2.p : (float2 *)e->d_spec.p;
             d.log2n = (uint32_t)e->log2n;
+            d.n = N;
             d.kind = e->cfg.device_kernel;
             d.gain_in = e->cfg.dk_gain;
             d.gain_out = e->cfg.dk_gain_outside;
@@ -777,6 +804,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         o.hop_first = k0;
         o.hop_count = kc;
         o.log2n = (uint32_t)e->log2n;
+        o.n = N;
         RC_HIP(rc::launch_ola(o, s, tail_only));
         launches += 2;
         return RC_OK;
@@ -807,6 +835,10 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
 
 // one hop described by p (spec / ybuf set) on the engine's stream, any supported window length
 int single_hop_forward(rc_engine *e, const rc::HopParams &p) {
+    if (e->gen) {
+        RC_HIP(rc::launch_gen(0, p, e->stream));
+        return RC_OK;
+    }
     if (e->log2n <= 14) {
         RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, p, e->stream));
         return RC_OK;
@@ -821,6 +853,11 @@ int single_hop_forward(rc_engine *e, const rc::HopParams &p) {
     return RC_OK;
 }
 int single_hop_resynth(rc_engine *e, const rc::HopParams &p) {
+    if (e->gen) {  // (p.spec holds the spectrum: magnitudes x phasors in place, then the inverse DFT)
+        RC_HIP(rc::launch_gen(1, p, e->stream));
+        RC_HIP(rc::launch_gen(2, p, e->stream));
+        return RC_OK;
+    }
     if (e->log2n <= 14) {
         RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, p, e->stream));
         return RC_OK;
@@ -905,9 +942,16 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
     rc_params par;
     int rc = derive(cfg, &par);
     if (rc) return rc;
-    const int log2n = ilog2_exact(cfg->window_len);
-    if (log2n < 5 || log2n > 16)
-        return fail(RC_EUNSUPPORTED, "window_len %u: the GPU path supports powers of two in [32, 65536]", cfg->window_len);
+    int log2n = ilog2_exact(cfg->window_len);
+    // Powers of two 32...65536 run the FFT kernels. Any other EVEN length up to 65536 (the reference takes any
+    // -w through rustfft: src/main.rs:34, src/fft.rs:27-29) runs as plain O(N^2) DFTs on the device: correct,
+    // not fast, and without a host frequency kernel.
+    const bool gen = log2n < 0 && cfg->window_len >= 4 && cfg->window_len <= 65536 && cfg->window_len % 2 == 0;
+    if (gen && cfg->kernel)
+        return fail(RC_EUNSUPPORTED, "window_len %u is not a power of two: host frequency kernels need one (device kernels work)", cfg->window_len);
+    if (!gen && (log2n < 5 || log2n > 16))
+        return fail(RC_EUNSUPPORTED, "window_len %u: the GPU path supports powers of two in [32, 65536] and even lengths in [4, 65536]", cfg->window_len);
+    if (gen) log2n = 0;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         (void)hipGetLastError();
@@ -925,6 +969,7 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
     e->cfg.window = nullptr;
     e->par = par;
     e->log2n = log2n;
+    e->gen = gen;
     e->device = cfg->device;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->seed_mixed = mix64(cfg->seed);
@@ -945,7 +990,7 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
         default_window = memcmp(d.data(), w.data(), N * sizeof(float)) == 0;
     }
     std::vector<float> hann_rot;
-    if (default_window && log2n >= 14) {
+    if (default_window && log2n >= 14 && !gen) {
         // thread t of the fused kernels touches samples 2 T q + 2 t + e: {cos, sin}(2 pi (2 t + e) / (len - 1)) for
         // the window (len = N) and the envelope (len = N / 2); T = 256 threads at N = 16384, 512 above
         const int threads = log2n == 14 ? 256 : 512;
@@ -964,6 +1009,14 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
     // wtab = exp(-2 pi i k / M) [M/2], rtab = exp(-2 pi i j / N) [M/4+1]. Larger windows run four
     // quarter FFTs of Ms = M/4 points: wtab is for Ms, rtab covers j <= Ms/2, t1 = exp(-2 pi i j / M).
     const bool big = log2n > 14;
+    std::vector<float2> twg;
+    if (gen) {
+        twg.resize(N);
+        for (uint32_t k = 0; k < N; ++k) {
+            const double a = -2.0 * M_PI * (double)k / (double)N;
+            twg[k] = make_float2((float)cos(a), (float)sin(a));
+        }
+    }
     const uint32_t Mf = big ? M / 4 : M;  // length of the in-LDS FFT
     std::vector<float2> wtab(std::max<uint32_t>(1, Mf / 2)), rtab(big ? Mf / 2 + 1 : M / 4 + 1), t1;
     for (uint32_t k = 0; k < Mf / 2; ++k) {
@@ -1013,6 +1066,10 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
     }
     RC_HIP_C(hipMemcpy(e->d_wtab, wtab.data(), wtab.size() * sizeof(float2), hipMemcpyHostToDevice));
     RC_HIP_C(hipMemcpy(e->d_rtab, rtab.data(), rtab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    if (gen) {
+        RC_HIP_C(hipMalloc((void **)&e->d_tw_gen, twg.size() * sizeof(float2)));
+        RC_HIP_C(hipMemcpy(e->d_tw_gen, twg.data(), twg.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
     if (big) {
         RC_HIP_C(hipMalloc((void **)&e->d_t1, t1.size() * sizeof(float2)));
         RC_HIP_C(hipMemcpy(e->d_t1, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice));
@@ -1042,6 +1099,7 @@ void rc_engine_destroy(rc_engine *e) {
     if (e->d_rtab) (void)hipFree(e->d_rtab);
     if (e->d_t1) (void)hipFree(e->d_t1);
     if (e->d_wtab_m) (void)hipFree(e->d_wtab_m);
+    if (e->d_tw_gen) (void)hipFree(e->d_tw_gen);
     e->d_in.release();
     e->d_out.release();
     e->d_spec.release();
@@ -1362,6 +1420,7 @@ int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float 
         d.in = (const float2 *)e->d_hop_out.p;
         d.out = e->cfg.device_kernel == RC_DK_SHIFT ? (float2 *)e->d_spec2.p : (float2 *)e->d_hop_out.p;
         d.log2n = (uint32_t)e->log2n;
+        d.n = N;
         const bool gain = e->cfg.device_kernel == RC_DK_GAIN;  // (the offline paths fold it into amp)
         d.kind = gain ? (uint32_t)RC_DK_BAND : e->cfg.device_kernel;
         d.gain_in = e->cfg.dk_gain;

@@ -57,6 +57,9 @@ struct HopParams {
     // spectrum modes (user-kernel path)
     float2 *spec;          // [n_channels][hop_count][N] natural-order spectrum
     float *ybuf;           // [n_channels][hop_count][N] windowed resynthesis output y_k
+    // window lengths that are not a power of two (launch_gen): N and exp(-2 pi i k / N), k < N
+    uint32_t n_generic;
+    const float2 *tw_generic;
 };
 
 struct OlaParams {
@@ -73,7 +76,8 @@ struct OlaParams {
     uint32_t n_channels;
     int64_t hop_first;
     int64_t hop_count;
-    uint32_t log2n;
+    uint32_t log2n;           // 0: the window length is `n` (not a power of two)
+    uint32_t n;
 };
 
 // Windows larger than one workgroup's LDS (N = 32768, 65536): the N/2-point FFT is split into
@@ -156,7 +160,8 @@ hipError_t launch_big4(int log2n, const HopParams &p, hipStream_t s);
 struct DevKernelParams {
     const float2 *in;    // [hops_total][N]
     float2 *out;         // may equal `in` for BAND; must differ for SHIFT
-    uint32_t log2n;
+    uint32_t log2n;      // 0: the window length is `n`
+    uint32_t n;
     uint32_t kind;       // 2 = band, 3 = shift (values of RC_DK_*)
     float gain_in, gain_out;
     uint32_t lo_bin, hi_bin;
@@ -164,5 +169,13 @@ struct DevKernelParams {
     uint64_t hops_total;
 };
 hipError_t launch_dev_kernel(const DevKernelParams &p, hipStream_t s);
+
+// Window lengths that are not a power of two (any even N): the reference accepts them through rustfft
+// (src/main.rs:34, src/fft.rs:27-29). They run as plain O(N^2) DFTs on the device - correct, not fast:
+//   stage 0: X[k] = sum_n x[k_hop step + n] w[n] e^{-2 pi i n k / N}   -> p.spec (natural order, all N bins)
+//   stage 1: Z[k] = |X[k]| e^{i theta(seed, c, hop, k)}                 (in place)
+//   stage 2: y[n] = Re(sum_k Z[k] e^{+2 pi i n k / N}) / N * w[n]       -> p.ybuf
+// followed by the gather-form overlap-add (launch_ola).
+hipError_t launch_gen(int stage, const HopParams &p, hipStream_t s);
 
 }  // namespace rc

@@ -23,6 +23,8 @@
 // No MFMA: this is an FFT/SFU/LDS-bound path, not a contraction.
 #include "rc_kernels.h"
 
+#include <algorithm>
+
 namespace rc {
 namespace {
 
@@ -2474,7 +2476,7 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
 
 // Overlap-add for the user-kernel path (gather form, two terms per output sample).
 __global__ __launch_bounds__(256) void ola_kernel(const OlaParams p) {
-    const uint32_t N = 1u << p.log2n, H = N / 2;
+    const uint32_t N = p.log2n ? 1u << p.log2n : p.n, H = N / 2;
     const int64_t hop_local = blockIdx.x;
     const uint32_t ch = blockIdx.y;
     const int64_t k = p.hop_first + hop_local;
@@ -2505,7 +2507,7 @@ __global__ __launch_bounds__(256) void ola_kernel(const OlaParams p) {
     }
 }
 __global__ __launch_bounds__(256) void ola_save_tail_kernel(const OlaParams p) {
-    const uint32_t N = 1u << p.log2n, H = N / 2;
+    const uint32_t N = p.log2n ? 1u << p.log2n : p.n, H = N / 2;
     const uint32_t ch = blockIdx.y;
     const float *yl = p.ybuf + ((size_t)ch * p.hop_count + (size_t)(p.hop_count - 1)) * N + H;
     float *t = p.tail + (size_t)ch * H;
@@ -3418,7 +3420,7 @@ hipError_t launch_big_cr(const BigOlaParams &p, hipStream_t s) {
 
 // Y = K(X) of the curated device kernels, one thread per bin (natural order, all N bins).
 __global__ __launch_bounds__(256) void dev_kernel(const DevKernelParams p) {
-    const uint32_t N = 1u << p.log2n, M = N / 2;
+    const uint32_t N = p.log2n ? 1u << p.log2n : p.n, M = N / 2;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t hop = blockIdx.y;
     if (j >= N) return;
@@ -3440,7 +3442,7 @@ __global__ __launch_bounds__(256) void dev_kernel(const DevKernelParams p) {
     p.out[hop * N + j] = y;
 }
 hipError_t launch_dev_kernel(const DevKernelParams &p, hipStream_t s) {
-    const uint32_t N = 1u << p.log2n;
+    const uint32_t N = p.log2n ? 1u << p.log2n : p.n;
     const uint64_t per_launch = 32768;  // grid.y limit
     for (uint64_t h0 = 0; h0 < p.hops_total; h0 += per_launch) {
         DevKernelParams q = p;
@@ -3469,6 +3471,90 @@ hipError_t launch_big4(int log2n, const HopParams &p, hipStream_t s) {
     if (log2n == 15) return launch_big4_r<32>(p, s);
     if (log2n == 16) return launch_big4_r<64>(p, s);
     return hipErrorInvalidValue;
+}
+
+// ---- window lengths that are not a power of two: O(N^2) DFTs (rc_kernels.h, launch_gen) -----------
+__global__ __launch_bounds__(256) void gen_fwd_kernel(const HopParams p) {
+    const uint32_t N = p.n_generic;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t hl = blockIdx.y;
+    const uint32_t ch = blockIdx.z;
+    const int64_t hop = p.hop_first + hl;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    GF src = (hop >= p.tail_hop_first) ? xt + (hop * (int64_t)p.step - p.tail_origin)
+                                       : xc + (hop * (int64_t)p.step - p.in_origin);
+    GF win = (GF)p.window;
+    GV2 tw = (GV2)p.tw_generic;
+    if (k >= N) return;
+    float ax = 0.f, ay = 0.f;
+    uint32_t idx = 0;
+    for (uint32_t n = 0; n < N; ++n) {
+        const float a = src[n] * win[n];  // (src/fft.rs:51-55)
+        const float2 w = ldg2(tw + idx);
+        ax = fmaf(a, w.x, ax);
+        ay = fmaf(a, w.y, ay);
+        idx += k;
+        if (idx >= N) idx -= N;
+    }
+    stg2((GV2W)p.spec + ((size_t)ch * p.hop_count + (size_t)hl) * N + k, make_float2(ax, ay));
+}
+__global__ __launch_bounds__(256) void gen_phase_kernel(const HopParams p) {
+    const uint32_t N = p.n_generic, half = N / 2;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t hl = blockIdx.y;
+    const uint32_t ch = blockIdx.z;
+    if (k >= N) return;
+    const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, p.hop_first + hl);
+    // frozen phase spec (rc_phase_theta): bins b < N/2 take the top 23 bits of hash(b), bins b + N/2 its low 16
+    const bool upper = k >= half;
+    const uint32_t h = phase_hash_x((upper ? k - half : k) * key.mul + key.k0);
+    const float u = upper ? (float)(h & 0xFFFFu) * (1.0f / 65536.0f) : (float)(h >> 9) * (1.0f / 8388608.0f);
+    const float th = u * 3.14159274101257324219f;
+    GV2W z = (GV2W)p.spec + ((size_t)ch * p.hop_count + (size_t)hl) * N + k;
+    const float2 X = ldg2((GV2)z);
+    const float m = sqrtf(X.x * X.x + X.y * X.y);
+    float sn, cs;
+    sincosf(th, &sn, &cs);
+    stg2(z, make_float2(m * cs, m * sn));  // src/fft.rs:65-68
+}
+__global__ __launch_bounds__(256) void gen_inv_kernel(const HopParams p) {
+    const uint32_t N = p.n_generic;
+    const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t hl = blockIdx.y;
+    const uint32_t ch = blockIdx.z;
+    if (n >= N) return;
+    GV2 z = (GV2)p.spec + ((size_t)ch * p.hop_count + (size_t)hl) * N;
+    GV2 tw = (GV2)p.tw_generic;
+    float acc = 0.f;
+    uint32_t idx = 0;
+    for (uint32_t k = 0; k < N; ++k) {
+        const float2 Z = ldg2(z + k), w = ldg2(tw + idx);
+        acc = fmaf(Z.x, w.x, fmaf(Z.y, w.y, acc));  // Re(Z conj(w)), w = (cos, -sin)
+        idx += n;
+        if (idx >= N) idx -= N;
+    }
+    ((GFW)p.ybuf)[((size_t)ch * p.hop_count + (size_t)hl) * N + n] = acc / (float)N * ((GF)p.window)[n];  // fft.rs:70-73
+}
+hipError_t launch_gen(int stage, const HopParams &p, hipStream_t s) {
+    const uint32_t N = p.n_generic;
+    const int64_t per = 32768;  // grid.y limit
+    for (int64_t h0 = 0; h0 < p.hop_count; h0 += per) {
+        HopParams q = p;
+        q.hop_first = p.hop_first + h0;
+        q.hop_count = p.hop_count;  // (row stride of spec / ybuf)
+        const unsigned ny = (unsigned)std::min<int64_t>(per, p.hop_count - h0);
+        // hop index inside the chunk = blockIdx.y + h0: shift the bases instead of the index
+        q.spec = p.spec ? p.spec + (size_t)h0 * N : nullptr;
+        q.ybuf = p.ybuf ? p.ybuf + (size_t)h0 * N : nullptr;
+        const dim3 grid((N + 255) / 256, ny, p.n_channels), block(256);
+        if (stage == 0) hipLaunchKernelGGL(gen_fwd_kernel, grid, block, 0, s, q);
+        else if (stage == 1) hipLaunchKernelGGL(gen_phase_kernel, grid, block, 0, s, q);
+        else hipLaunchKernelGGL(gen_inv_kernel, grid, block, 0, s, q);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only) {

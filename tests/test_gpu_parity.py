@@ -866,6 +866,47 @@ def test_unsupported_configs_fail_loudly():
     ra = _engine_mod()
     from rocoder_amd import _lib
 
-    with pytest.raises(_lib.RocoderError) as ei:
-        ra.stretch(np.zeros((1, 5000), np.float32), window_len=1000)
+    with pytest.raises(_lib.RocoderError) as ei:  # odd window lengths
+        ra.stretch(np.zeros((1, 5000), np.float32), window_len=1001)
     assert ei.value.code == _lib.RC_EUNSUPPORTED
+    with pytest.raises(_lib.RocoderError) as ei:  # a host kernel on a window that is not a power of two
+        ra.stretch(np.zeros((1, 5000), np.float32), window_len=1000, kernel=_kernel_for(2.0))
+    assert ei.value.code == _lib.RC_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("N,L,f,p,ch", [(1000, 20000, 4.0, 1, 2), (3000, 12000, 8.0, 1, 1), (500, 9000, 1.5, 2, 1),
+                                        (12000, 16000, 4.0, 1, 1), (6000, 30000, 2.0, 1, 1),
+                                        (1000, 15000, 3.0, -2, 1), (36, 700, 0.3, 1, 1)])
+def test_window_lengths_that_are_not_powers_of_two(N, L, f, p, ch):
+    """The reference accepts any -w (rustfft: src/main.rs:34, src/fft.rs:27-29). Even lengths that are not a
+    power of two run as O(N^2) DFTs on the device (rc_kernels.h, launch_gen): same results, not the same speed."""
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, L) for c in range(ch)])
+    got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=0x5EED)
+    ref = oc.stretch_offline(x, N, f, 1.0, p, seed=0x5EED)
+    for c in range(ch):
+        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}")
+
+
+def test_non_power_of_two_window_refft_device_kernel_and_streaming():
+    ra = _engine_mod()
+    N = 1500
+    x = onp.synth_input(1, 30000)
+    w = oc.hanning(N)
+    r = ra.ReFFT(w, seed=3, channel_index=1)
+    X = r.forward_fft(x[:N])
+    Xo = oc.ReFFT(w).forward_fft(x[:N])
+    assert rms(np.abs(X - Xo)) <= 1e-5 * rms(np.abs(Xo)) + 1e-6
+    y = r.resynth(x[:N], hop=5)
+    assert_parity(y, oc.ReFFT(w).resynth(x[:N], oc.phase_key(3, 1, 5)), "resynth 1500")
+    band = ra.stretch(x[None], window_len=N, factor=4.0, seed=2, device_kernel=("band", 10, 200, 1.5, 0.2))
+    assert_parity(band, oc.stretch_offline(x[None], N, 4.0, 1.0, 1, seed=2, kernel=_np_band(10, 200, 1.5, 0.2)), "band 1500")
+    q: "queue.Queue" = queue.Queue()
+    s = ra.Stretcher(ra.AudioSpec(1, 44100), q, 4.0, 1.0, 1, w, seed=8)
+    for i in range(0, x.size, 4001):
+        q.put(x[i:i + 4001])
+    q.put(None)
+    wins = []
+    while not s.is_done():
+        wins.append(s.next_window().copy())
+    assert_parity(np.concatenate(wins), oc.stretch_offline(x[None], N, 4.0, 1.0, 1, seed=8)[0], "streaming 1500")
