@@ -100,7 +100,7 @@ def test_compute_fails_loudly_without_gpu():
 
 
 def test_unsupported_window_is_reported_not_faked():
-    cfg, _k = make_config(window_len=1000)
+    cfg, _k = make_config(window_len=1001)  # odd lengths (even ones that are not a power of two run as DFTs)
     h = C.c_void_p()
     rc = _lib.lib().rc_engine_create(C.byref(cfg), C.byref(h))
     assert rc == _lib.RC_EUNSUPPORTED and not h.value
