@@ -1905,20 +1905,7 @@ __device__ __forceinline__ void wave_fence() {
 #ifndef RC_DEFER_STORE
 #define RC_DEFER_STORE 0
 #endif
-#ifndef RC_T_SDST
-#define RC_T_SDST 1
-#endif
-#ifndef RC_T_F1
-#define RC_T_F1 1
-#endif
-#ifndef RC_T_PAIR
-#define RC_T_PAIR 1
-#endif
-#if RC_T_PAIR
 #define HOP4_PAIR pair_regs_pk4
-#else
-#define HOP4_PAIR pair_regs_pk
-#endif
 #define HOP4_BAR()                                                                    \
     do {                                                                              \
         if (RC_ABLATE & 32) break;                                                    \
@@ -2025,14 +2012,10 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
         const int64_t g0 = kk * (int64_t)H;
         if constexpr (PITCH1) {
             // uniform destination in SGPRs + 32-bit lane offset (no 64-bit address arithmetic per store)
-#if RC_T_SDST
             const unsigned long long da = (unsigned long long)(outc + (g0 - p.out_origin));
             const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);  // (the builtin returns int:
             const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));  // widen as unsigned)
             GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
-#else
-            GFW dst = outc + (g0 - p.out_origin);
-#endif
             if (RC_ABLATE & 4096) dst = outc + ((g0 - p.out_origin) & 0x3FFFF);  // timing only: 1 MiB target
             if (RC_ABLATE & 2048) {  // timing only: the same bytes as 8 x 16-byte stores (wrong places)
                 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -2121,7 +2104,6 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
                 xr1[q] = (src + 2 * T * q)[lane2 + 1];
             }
             const v2f cb = to_v(lds[T_H + 2 * tid]), sb = to_v(lds[T_H + 2 * tid + 1]);
-#if RC_T_F1
             // stage 0 pairs registers brev5(q) and brev5(q + 16) = brev5(q) + 1: a +- b with a = x_q w_q and
             // b = x_{q+16} w_{q+16} is one multiply and two FMAs
 #pragma unroll
@@ -2149,16 +2131,6 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             } else {
                 dit_stages<32, m, 1, 4, 0, false, false>(v);
             }
-#else
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                const v2f wq = __builtin_elementwise_fma(v2f{HANN_W14.s[q], HANN_W14.s[q]}, sb,
-                               __builtin_elementwise_fma(v2f{HANN_W14.c[q], HANN_W14.c[q]}, cb, half2));
-                v[brev_c(q, 5)] = v2f{xr0[q], xr1[q]} * wq;
-            }
-            st.mark(0);
-            dit_stages<32, m, 0, 4, 0, false, false>(v);
-#endif
             st.mark(1);
         }
         // ---- E1 (cross-wave), round A: position bit 4 clear. Own region (last read by this wave in
@@ -2387,18 +2359,11 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
 
         // ---- epilogue: synthesis window, overlap-add with the carried tail, store
         const v2f cbW = to_v(lds[T_H + 2 * tid]), sbW = to_v(lds[T_H + 2 * tid + 1]);
-#if RC_T_PAIR
         const v2f half2k = {(float)(0.5 * HANN_KAPPA), (float)(0.5 * HANN_KAPPA)};
 #pragma unroll
         for (int q = 0; q < P; ++q)
             y[q] *= __builtin_elementwise_fma(v2f{HANN_W14K.s[q], HANN_W14K.s[q]}, sbW,
                     __builtin_elementwise_fma(v2f{HANN_W14K.c[q], HANN_W14K.c[q]}, cbW, half2k));
-#else
-#pragma unroll
-        for (int q = 0; q < P; ++q)
-            y[q] *= __builtin_elementwise_fma(v2f{HANN_W14.s[q], HANN_W14.s[q]}, sbW,
-                    __builtin_elementwise_fma(v2f{HANN_W14.c[q], HANN_W14.c[q]}, cbW, half2));
-#endif
         if (k >= k_begin) {
             if (stash_first && k == k_begin) {
                 int t2 = tid;
