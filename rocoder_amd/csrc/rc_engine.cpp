@@ -485,6 +485,37 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
     return RC_OK;
 }
 
+#ifdef RC_STAMP_DUMP
+// diagnostic builds only: per-wave phase cycle totals of the last launch -> $ROCODER_STAMPS (text)
+static int dump_stamps(rc_engine *e, size_t n_dbg, hipStream_t s, int64_t hop_count, uint32_t run_len) {
+    const char *path = getenv("ROCODER_STAMPS");
+    if (!path) return RC_OK;
+    std::vector<unsigned> h(n_dbg);
+    RC_HIP(hipStreamSynchronize(s));
+    RC_HIP(hipMemcpy(h.data(), e->d_spec.p, n_dbg * sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (FILE *f = fopen(path, "w")) {
+        double sum[32] = {0};
+        size_t nw = 0;
+        for (size_t w = 0; w < n_dbg / 32; ++w) {
+            bool any = false;
+            for (int i = 0; i < 32; ++i) any |= h[w * 32 + i] != 0;
+            if (!any) continue;
+            nw++;
+            for (int i = 0; i < 32; ++i) sum[i] += h[w * 32 + i];
+        }
+        fprintf(f, "waves %zu hops %lld run_len %u\n", nw, (long long)hop_count, run_len);
+        for (int i = 0; i < 32; ++i) fprintf(f, "phase %2d mean_cycles_per_wave %.0f\n", i, nw ? sum[i] / nw : 0.0);
+        for (size_t w = 0; w < 16 && w < n_dbg / 32; ++w) {  // the waves of the first workgroup(s), one per line
+            fprintf(f, "wave %2zu:", w);
+            for (int i = 0; i < 16; ++i) fprintf(f, " %u", h[w * 32 + i]);
+            fprintf(f, "\n");
+        }
+        fclose(f);
+    }
+    return RC_OK;
+}
+#endif
+
 // The core: compute hops [hop_first, hop_first+hop_count) of n_channels channels whose samples
 // live on the device, writing the decimated overlap-add at d_out (absolute F index out_origin).
 int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origin, int64_t in_len,
@@ -596,25 +627,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         if (timed) RC_HIP(hipEventRecord(e->ev0[e->timed_calls % rc_engine::kRing], s));
         RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FUSED, p, s));
 #ifdef RC_STAMP_DUMP
-        if (const char *path = getenv("ROCODER_STAMPS")) {
-            std::vector<unsigned> h(n_dbg);
-            RC_HIP(hipStreamSynchronize(s));
-            RC_HIP(hipMemcpy(h.data(), e->d_spec.p, n_dbg * sizeof(unsigned), hipMemcpyDeviceToHost));
-            if (FILE *f = fopen(path, "w")) {
-                double sum[32] = {0};
-                size_t nw = 0;
-                for (size_t w = 0; w < n_dbg / 32; ++w) {
-                    bool any = false;
-                    for (int i = 0; i < 32; ++i) any |= h[w * 32 + i] != 0;
-                    if (!any) continue;
-                    nw++;
-                    for (int i = 0; i < 32; ++i) sum[i] += h[w * 32 + i];
-                }
-                fprintf(f, "waves %zu hops %lld run_len %u\n", nw, (long long)hop_count, p.run_len);
-                for (int i = 0; i < 32; ++i) fprintf(f, "phase %2d mean_cycles_per_wave %.0f\n", i, nw ? sum[i] / nw : 0.0);
-                fclose(f);
-            }
-        }
+        if (int rcd = dump_stamps(e, n_dbg, s, hop_count, p.run_len)) return rcd;
 #endif
         if (timed) {
             RC_HIP(hipEventRecord(e->ev1[e->timed_calls % rc_engine::kRing], s));
@@ -643,8 +656,17 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
             if (int rcs = e->d_ybuf.reserve((size_t)p.runs_per_channel * n_channels * H * sizeof(float))) return rcs;
             p.ybuf = (float *)e->d_ybuf.p;
         }
+#ifdef RC_STAMP_DUMP
+        const size_t n_dbg = (size_t)p.runs_per_channel * n_channels * 8 * 32;
+        if (int rcd = e->d_spec.reserve(n_dbg * sizeof(unsigned))) return rcd;
+        RC_HIP(hipMemsetAsync(e->d_spec.p, 0, n_dbg * sizeof(unsigned), s));
+        p.spec = (float2 *)e->d_spec.p;
+#endif
         if (timed) RC_HIP(hipEventRecord(e->ev0[e->timed_calls % rc_engine::kRing], s));
         RC_HIP(rc::launch_big4(e->log2n, p, s));
+#ifdef RC_STAMP_DUMP
+        if (int rcd = dump_stamps(e, n_dbg, s, hop_count, p.run_len)) return rcd;
+#endif
         if (timed) {
             RC_HIP(hipEventRecord(e->ev1[e->timed_calls % rc_engine::kRing], s));
             e->timed_calls++;

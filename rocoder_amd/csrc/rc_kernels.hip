@@ -2847,6 +2847,22 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
 #ifndef RC_B4_LB
 #define RC_B4_LB 32
 #endif
+#ifndef RC_B4_TAILREG_MAX
+#define RC_B4_TAILREG_MAX 32  // largest R whose carried tail lives in registers (above: per-workgroup scratch)
+#endif
+#ifndef RC_B4_LGKM
+#define RC_B4_LGKM 1
+#endif
+// the exchange barriers order LDS traffic only: global stores of the epilogue (this thread's own output and tail
+// addresses) may still be in flight when the next hop starts
+#define BIG4_BAR()                                                                       \
+    do {                                                                                 \
+        if (RC_B4_LGKM) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
+        else __syncthreads();                                                            \
+    } while (0)
+#ifndef RC_B4_EB
+#define RC_B4_EB 4
+#endif
 #ifndef RC_B4_TPRE
 #define RC_B4_TPRE 0
 #endif
@@ -2860,7 +2876,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
     constexpr int b = clog2(R), m = b + 9, LOG2N = m + 1, M = 1 << m, H = M, T = BIG4_T;
     constexpr int RES = 1 << (b + 5), G = R / 32, NS = R / 16, PH = R / 2;
     constexpr int T_A = BIG4_XBUF, T_R = T_A + RES / 2 + 1, SCR = T_R + RES / 2 + 1;
-    constexpr bool TAIL_GLOBAL = R > 32;
+    constexpr bool TAIL_GLOBAL = R > RC_B4_TAILREG_MAX;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const uint32_t run = blockIdx.x % p.runs_per_channel;
@@ -2873,6 +2889,12 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
     GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
     GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
     GV2W tsc = (GV2W)p.ybuf + (size_t)blockIdx.x * (H / 2);  // TAIL_GLOBAL: this workgroup's tail scratch
+    if constexpr (TAIL_GLOBAL) {  // uniform base in SGPRs + a 32-bit lane offset: no 64-bit address per access
+        const unsigned long long ta = (unsigned long long)tsc;
+        const unsigned tlo = __builtin_amdgcn_readfirstlane((unsigned)ta);
+        const unsigned thi = __builtin_amdgcn_readfirstlane((unsigned)(ta >> 32));
+        tsc = (GV2W)(((unsigned long long)thi << 32) | tlo);
+    }
     const unsigned lane2 = 2u * (unsigned)tid;
     const uint32_t pitch = PITCH1 ? 1u : p.pitch;
     const int wv = tid >> 6;
@@ -2895,14 +2917,18 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
     } else {
 #pragma unroll
-        for (int q = 0; q < PH; ++q) stg2(tsc + tid + T * q, make_float2(0.f, 0.f));
+        for (int q = 0; q < PH; ++q) stg2(tsc + T * q + (unsigned)tid, make_float2(0.f, 0.f));
     }
     // thread identities
     const int lf = tid & 31, uu = tid >> 5;   // F2
     const int l4 = tid & 15, hi = tid >> 4;   // I2
     const bool is0 = tid == 0;
+    Stamps stp;
+    stp.init();
     for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+        int tt = tid;  // per-hop opaque copy for the scratch addresses (hoisted, they would be 2 PH live VGPRs)
+        opaque(tt);
         v2f v[R];
         {   // register brev_b(q) := z[q * T + t] * window
             GF src = hop_src(p, xc, xt, k);
@@ -2941,8 +2967,10 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                     v[brev_c(q0 + q, b)] = v2f{xr0[q], xr1[q]} * wq;
                 }
             }
+            stp.mark(0);
             dit_g<R, 0, b - 1, 0, false, false>(v);
         }
+        stp.mark(1);
         // ---- E1: F1 -> F2, round g moves the registers with position bit 5 = g
         v2f w[R];
         {
@@ -2951,14 +2979,15 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             const int b1l = lf + (uu << 10) + uu;                        // e1(lf | j << 5 | uu << 10) = (j << 5) + this
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                __syncthreads();
+                BIG4_BAR();
 #pragma unroll
                 for (int q = 0; q < 32; ++q) lds[b1s + q] = to_f2(v[32 * g + q]);
-                __syncthreads();
+                BIG4_BAR();
 #pragma unroll
                 for (int j = 0; j < 32; ++j) w[32 * g + j] = to_v(lds[b1l + (j << 5)]);
             }
         }
+        stp.mark(2);
         {   // F2: stages b..b+4 on each group; base W_RES^(lf | g << 5) = W_M^(16 lf) * (g ? W_64 : 1)
             const v2f wf0 = to_v(lds[T_A + 16 * lf]);
 #pragma unroll
@@ -2971,19 +3000,20 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 for (int j = 0; j < 32; ++j) w[32 * g + j] = grp[j];
             }
         }
+        stp.mark(3);
         // ---- E2: F2 -> F3. slot = (residue mod 1024) | uu << 10; R = 64: round 0 = residues < 1024
         v2f st[NS][16];
         {
             const int b2s = lf | (uu << 10);
 #pragma unroll
             for (int rnd = 0; rnd < G; ++rnd) {
-                __syncthreads();
+                BIG4_BAR();
 #pragma unroll
                 for (int kk = 0; kk < 32; ++kk) {
                     if (R == 32) lds[b2s + (kk << 5)] = to_f2(w[kk]);
                     else lds[b2s + ((kk >> 4) << 5) + ((kk & 15) << 6)] = to_f2(w[32 * (kk >> 4) + 16 * rnd + (kk & 15)]);
                 }
-                __syncthreads();
+                BIG4_BAR();
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     if (R == 64 && ((s & 1) != rnd)) continue;
@@ -2994,6 +3024,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 }
             }
         }
+        stp.mark(4);
         // ---- F3 on every set, middle stage on every (A, B) pair of sets, I1
 #pragma unroll
         for (int gp = 0; gp < NS / 2; ++gp) {
@@ -3075,11 +3106,12 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 vb[q] = pb[q];
             }
         }
+        stp.mark(5);
         // ---- E3: I1 -> I2. element P = q' | brev_{b+5}(residue) << 4; R = 64: P4 (= residue >= 1024) is the round
         {
 #pragma unroll
             for (int rnd = 0; rnd < G; ++rnd) {
-                __syncthreads();
+                BIG4_BAR();
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     if (R == 64 && ((s & 1) != rnd)) continue;
@@ -3092,7 +3124,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) lds[base + q] = to_f2(st[s][q]);
                 }
-                __syncthreads();
+                BIG4_BAR();
 #pragma unroll
                 for (int kk = 0; kk < 32; ++kk) {
                     // R = 32: register kk = P4..P8; R = 64: kk = (group g = P14) << 4 | (P5..P8), P4 = rnd
@@ -3104,6 +3136,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 }
             }
         }
+        stp.mark(6);
         {   // I2: inverse stages 4..8 on each group, base W_512^l4 = W_M^(l4 R)
             const v2f wf = to_v(lds[T_A + l4 * R]);
 #pragma unroll
@@ -3116,29 +3149,32 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 for (int j = 0; j < 32; ++j) v[32 * g + j] = grp[j];
             }
         }
+        stp.mark(7);
         // ---- E4: I2 -> I3 (registers = P9.., thread = P0..P8), round g = P14
         v2f y[R];
         {
             const int b4s = l4 | (hi << 9);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                __syncthreads();
+                BIG4_BAR();
 #pragma unroll
                 for (int j = 0; j < 32; ++j) lds[b4s + (j << 4)] = to_f2(v[32 * g + j]);
-                __syncthreads();
+                BIG4_BAR();
 #pragma unroll
                 for (int q = 0; q < 32; ++q) y[q + 32 * g] = to_v(lds[tid + (q << 9)]);
             }
         }
+        stp.mark(8);
         // R = 64: the carried tail comes back from the scratch; requested here, behind the last exchange, so that
         // its latency hides under I3 (v is dead: there are registers for it)
         constexpr bool TPRE = TAIL_GLOBAL && RC_B4_TPRE;
         v2f tpre[TPRE ? PH : 1];
         if constexpr (TPRE) {
 #pragma unroll
-            for (int q = 0; q < PH; ++q) tpre[q] = to_v(ldg2((GV2)tsc + tid + T * q));
+            for (int q = 0; q < PH; ++q) tpre[q] = to_v(ldg2((GV2)tsc + T * q + (unsigned)tt));
         }
         dit_g<R, 9, m - 1, 9, true, true>(y, to_v(lds[T_A + tid]));
+        stp.mark(9);
         // ---- epilogue: synthesis window, overlap-add, store (tail in registers or in the scratch)
         {
             GF win = per_hop(p.window);
@@ -3158,11 +3194,25 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             const int64_t g0 = k * (int64_t)H;
             GFW dst = outc + (g0 / (int64_t)pitch - p.out_origin);
             const uint32_t kr = (uint32_t)(g0 % pitch);
-            constexpr int EB = R > 32 ? 4 : 8;  // batch of table loads in flight (register budget)
+            constexpr int EB = R > 32 ? RC_B4_EB : 8;  // batch of table / tail loads in flight (register budget)
+            constexpr bool TPIPE = TAIL_GLOBAL && !TPRE;  // tail loads one batch ahead of their use
+            v2f tnx[TPIPE ? EB : 1];
+            if constexpr (TPIPE) {
+#pragma unroll
+                for (int q = 0; q < EB; ++q) tnx[q] = to_v(ldg2((GV2)tsc + T * q + (unsigned)tt));
+            }
 #pragma unroll
             for (int q0 = 0; q0 < PH; q0 += EB) {
                 float wr0[EB], wr1[EB], wt0[EB], wt1[EB], e0[EB], e1[EB];
                 v2f tq[EB];
+                if constexpr (TPIPE) {
+#pragma unroll
+                    for (int q = 0; q < EB; ++q) tq[q] = tnx[q];
+                    if (q0 + EB < PH) {
+#pragma unroll
+                        for (int q = 0; q < EB; ++q) tnx[q] = to_v(ldg2((GV2)tsc + T * (q0 + EB + q) + (unsigned)tt));
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < EB; ++q) {
                     if constexpr (!HANN) {
@@ -3182,7 +3232,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                         wr0[q] = wh.x, wr1[q] = wh.y, wt0[q] = wt.x, wt1[q] = wt.y, e0[q] = ev.x, e1[q] = ev.y;
                     }
                     if constexpr (TPRE) tq[q] = tpre[q0 + q];
-                    else if constexpr (TAIL_GLOBAL) tq[q] = to_v(ldg2((GV2)tsc + tid + T * (q0 + q)));
+                    else if constexpr (TAIL_GLOBAL) {}
                     else tq[q] = tail[q0 + q];
                 }
 #pragma unroll
@@ -3201,12 +3251,19 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                             if (d1 * pitch == a1) dst[d1] = o.y;
                         }
                     }
-                    if constexpr (TAIL_GLOBAL) stg2(tsc + tid + T * (q0 + q), to_f2(nt));
+                    if constexpr (TAIL_GLOBAL) stg2(tsc + T * (q0 + q) + (unsigned)tt, to_f2(nt));
                     else tail[q0 + q] = nt;
                 }
             }
         }
+        stp.mark(10);
     }
+#if RC_STAMP
+    if ((tid & 63) == 0 && p.spec) {
+        unsigned *dbg = (unsigned *)p.spec + ((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * 32;
+        for (int i = 0; i < 32; ++i) dbg[i] = stp.acc[i];
+    }
+#endif
 }
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
