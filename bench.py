@@ -41,6 +41,7 @@ CHANNELS = 2
 SAMPLE_RATE = 44100
 L_IN = 26_460_000
 SEED = 0x5EED
+CONCAT_TIMEOUT_S = float(os.environ.get("ROCODER_BENCH_CONCAT_TIMEOUT", "120"))  # watchdog of the post-measurement concat region (N > 1)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 LDS_READ_PEAK_GBS = 150e3    # MI355X_MICROARCH.md §LDS: ds_read_b64/b128, every CU streaming
 LDS_WRITE_PEAK_GBS = 45e3    # same: 38-51 TB/s for ds_write_b32..b128
@@ -148,15 +149,34 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # ROCODER_BENCH_REHEARSAL=1 (dev only, never the driver's command): every rank on cuda:0 over gloo, to walk the
+    # N > 1 shard plan / timing code on a one-GPU box. RCCL refuses two ranks on one device, so the concat region
+    # reports an error there; the JSON line is marked "rehearsal" and is not a measurement.
+    rehearsal = os.environ.get("ROCODER_BENCH_REHEARSAL") in ("1", "hang")  # "hang": stall the concat region (watchdog test)
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: RCCL barrier/all-reduce
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    def note(msg):  # progress on stderr in rehearsals only
+        if rehearsal:
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    def max_over_ranks(v):
+        if dist is None:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device="cpu" if rehearsal else device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
     import rocoder_amd
     from rocoder_amd import _lib
@@ -166,7 +186,7 @@ def main():
     # ONE job for all ranks: same seed, same (replicated, device-generated) input of world x L samples
     length = L_IN * world
     eng = rocoder_amd.Engine(window_len=WINDOW, factor=FACTOR, pitch_multiple=PITCH,
-                             sample_rate=SAMPLE_RATE, channels=CHANNELS, seed=SEED, device=local_rank)
+                             sample_rate=SAMPLE_RATE, channels=CHANNELS, seed=SEED, device=dev_index)
     x = synth_on_device(torch, device, CHANNELS, length)
     wout = eng.params.window_out_len
     n_out = eng.output_len(length)          # per channel, whole job
@@ -191,7 +211,9 @@ def main():
 
     # a real (non-default) stream: the engine launches its kernels on exactly this stream
     stream = torch.cuda.Stream(device)
+    note(f"plan {[(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan]}")
     barrier()
+    note("first barrier passed")
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
             step()
@@ -219,10 +241,8 @@ def main():
         per_call = eng.kernel_times(min(64, args.steps * max(1, len(mine))))
         kernel_ms_median = statistics.median(per_call)
         kernel_ms_mean = sum(per_call) / len(per_call)
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    note(f"timed region done: {dt:.4f} s")
+    dt = max_over_ranks(dt)
 
     extras = {}
     concat = None
@@ -242,34 +262,6 @@ def main():
             stream.synchronize()
             extras["copy_GBs"] = 2.0 * 4.0 * n_copy * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
             del a, b
-            if dist is not None and world > 1:
-                # the one collective of the path: concat of the shards on rank 0, straight into the final
-                # layout (stretch_sharded). Timed as compute + concat per step. A failure here must not cost
-                # the main line: it is reported inside config.concat instead.
-                try:
-                    full = torch.empty((CHANNELS, n_out), dtype=torch.float32, device=device) if rank == 0 else None
-                    k2 = max(2, min(5, args.steps))
-                    stretch_sharded(compute, CHANNELS, nwin, wout, dst=0, full=full)
-                    barrier()
-                    tc = time.perf_counter()
-                    for _ in range(k2):
-                        stretch_sharded(compute, CHANNELS, nwin, wout, dst=0, full=full)
-                    barrier()
-                    dtc = time.perf_counter() - tc
-                    tt = torch.tensor([dtc], dtype=torch.float64, device=device)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    dtc = float(tt.item())
-                    concat = {
-                        "steps": k2,
-                        "ms_per_step_with_concat": round(dtc / k2 * 1e3, 4),
-                        "value_with_concat": round(float(n_out) * CHANNELS * k2 / dtc / 1e6, 1),
-                        "bytes_moved_to_rank0": int((n_out * CHANNELS - (my_samples if rank == 0 else 0)) * 4),
-                        "how": "grouped RCCL send/recv of each shard into its view of the final [channels, n_out] "
-                               "tensor on rank 0 (root-inbound-bound); no pad, no staging copy",
-                    }
-                    del full
-                except Exception as ex:  # noqa: BLE001
-                    concat = {"error": f"{type(ex).__name__}: {ex}"[:300]}
         if world == 1:
             # PCIe-inclusive (host buffers in and out): never `value`, reported for SURVEY §8 d1
             xh = x.cpu().numpy()
@@ -278,6 +270,7 @@ def main():
             extras["e2e_pcie_Msamples_s"] = yh.size / (time.perf_counter() - t_e) / 1e6
             del xh, yh
 
+    res = None
     if rank == 0:
         total_samples = float(n_out) * CHANNELS * args.steps
         value = total_samples / dt / 1e6
@@ -334,7 +327,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo, not a measurement)",
             "config": {
                 "workload": f"BASELINE configs[1]: stereo 44.1 kHz, window=16384, factor=8, pitch=1, "
                             f"L={length}/ch ({world} x 26460000), inputs resident in HBM",
@@ -348,8 +341,6 @@ def main():
             },
             "roofline": roof,
         }
-        if concat:
-            res["config"]["concat"] = concat
         if "e2e_pcie_Msamples_s" in extras:
             res["config"]["e2e_pcie_Msamples_s"] = round(extras["e2e_pcie_Msamples_s"], 1)
         if world == 1 and not args.no_cpu_baseline:
@@ -359,10 +350,70 @@ def main():
             if many:
                 res["cpu_baseline_all_cores"] = many
                 res["config"]["x_cpu_all_cores"] = round(value / many["value"], 1)
-        os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    # ---- the one collective of the path, AFTER the main line is complete and under a watchdog: a concat that hangs
+    # (it is the only code here that a one-GPU box cannot rehearse) must not cost the measurement
+    import threading
+
+    lock = threading.Lock()
+    emitted = [False]
+
+    def emit():
+        with lock:
+            if rank == 0 and not emitted[0]:
+                if concat:
+                    res["config"]["concat"] = concat
+                os.write(real_stdout, (json.dumps(res) + "\n").encode())
+            emitted[0] = True
+
+    def watchdog():
+        nonlocal concat
+        if not emitted[0]:
+            concat = {"error": f"concat region did not finish within {CONCAT_TIMEOUT_S} s; the main line is unaffected"}
+        emit()
+        os._exit(0)
+
+    timer = threading.Timer(CONCAT_TIMEOUT_S, watchdog)
+    timer.daemon = True
+    if world > 1:
+        timer.start()
+    if not args.no_extras:
+        with torch.cuda.stream(stream):
+            if dist is not None and world > 1 and rehearsal:
+                concat = {"skipped": "rehearsal: gloo has no device-to-device send/recv"}
+                if os.environ.get("ROCODER_BENCH_REHEARSAL") == "hang":
+                    concat = None
+                    time.sleep(1e6)
+            elif dist is not None and world > 1:
+                # the one collective of the path: concat of the shards on rank 0, straight into the final
+                # layout (stretch_sharded). Timed as compute + concat per step. A failure here must not cost
+                # the main line: it is reported inside config.concat instead.
+                try:
+                    full = torch.empty((CHANNELS, n_out), dtype=torch.float32, device=device) if rank == 0 else None
+                    k2 = max(2, min(5, args.steps))
+                    stretch_sharded(compute, CHANNELS, nwin, wout, dst=0, full=full)
+                    barrier()
+                    tc = time.perf_counter()
+                    for _ in range(k2):
+                        stretch_sharded(compute, CHANNELS, nwin, wout, dst=0, full=full)
+                    barrier()
+                    dtc = time.perf_counter() - tc
+                    dtc = max_over_ranks(dtc)
+                    concat = {
+                        "steps": k2,
+                        "ms_per_step_with_concat": round(dtc / k2 * 1e3, 4),
+                        "value_with_concat": round(float(n_out) * CHANNELS * k2 / dtc / 1e6, 1),
+                        "bytes_moved_to_rank0": int((n_out * CHANNELS - (my_samples if rank == 0 else 0)) * 4),
+                        "how": "grouped RCCL send/recv of each shard into its view of the final [channels, n_out] "
+                               "tensor on rank 0 (root-inbound-bound); no pad, no staging copy",
+                    }
+                    del full
+                except Exception as ex:  # noqa: BLE001
+                    concat = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    emit()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    timer.cancel()
 
 
 if __name__ == "__main__":
