@@ -552,6 +552,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     p.ch_first = ch_first;
     p.n_channels = n_channels;
     const uint32_t N = e->par.window_len, H = N / 2;
+    rc::PrepParams prep{};  // ONE small launch in front of the job: the padded tail + the seam's run counter
     {
         // Hops whose window runs past the end of the input read a zero-padded copy of the input
         // tail (src/stretcher.rs:129-132: resize(n, 0.0)); the kernels never bounds-check.
@@ -572,13 +573,12 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
             const int64_t real = std::max<int64_t>(0, std::min<int64_t>(end_abs - t0, (int64_t)tail_len));
             int rc = e->d_xtail.reserve((size_t)n_channels * tail_len * sizeof(float));
             if (rc) return rc;
-            RC_HIP(hipMemsetAsync(e->d_xtail.p, 0, (size_t)n_channels * tail_len * sizeof(float), s));
-            if (real > 0)
-                RC_HIP(hipMemcpy2DAsync(e->d_xtail.p, tail_len * sizeof(float),
-                                        d_in + (t0 - in_origin),
-                                        std::max<size_t>(in_stride, (size_t)real) * sizeof(float),
-                                        (size_t)real * sizeof(float), n_channels,
-                                        hipMemcpyDeviceToDevice, s));
+            prep.xtail = (float *)e->d_xtail.p;
+            prep.tail_len = tail_len;
+            prep.src = d_in + (t0 - in_origin);
+            prep.src_stride = in_stride;
+            prep.real = (size_t)real;
+            prep.n_channels = n_channels;
             p.xtail = (const float *)e->d_xtail.p;
             p.tail_stride = tail_len;
             p.tail_origin = t0;
@@ -613,7 +613,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
                     RC_HIP(hipMemsetAsync(e->d_seam_flag.p, 0, e->d_seam_flag.cap, s));
                     e->seam_epoch = 0;
                 }
-                RC_HIP(hipMemsetAsync(e->d_run_counter.p, 0, sizeof(uint32_t), s));
+                prep.run_counter = (uint32_t *)e->d_run_counter.p;
                 if (++e->seam_epoch == 0) {  // wrapped: start over with clean flags
                     RC_HIP(hipMemsetAsync(e->d_seam_flag.p, 0, e->d_seam_flag.cap, s));
                     e->seam_epoch = 1;
@@ -624,6 +624,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
                 p.seam_epoch = e->seam_epoch;
             }
         }
+        RC_HIP(rc::launch_prep(prep, s));
         if (timed) RC_HIP(hipEventRecord(e->ev0[e->timed_calls % rc_engine::kRing], s));
         RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FUSED, p, s));
 #ifdef RC_STAMP_DUMP
@@ -662,6 +663,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         RC_HIP(hipMemsetAsync(e->d_spec.p, 0, n_dbg * sizeof(unsigned), s));
         p.spec = (float2 *)e->d_spec.p;
 #endif
+        RC_HIP(rc::launch_prep(prep, s));
         if (timed) RC_HIP(hipEventRecord(e->ev0[e->timed_calls % rc_engine::kRing], s));
         RC_HIP(rc::launch_big4(e->log2n, p, s));
 #ifdef RC_STAMP_DUMP
@@ -685,6 +687,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     //   * negative pitch multiples: linear-interpolating overlap-add (src/resampler.rs:20-35).
     // Without a user kernel the hop before the range is recomputed to seed the tail, so ranges and
     // streaming batches do not depend on call history.
+    RC_HIP(rc::launch_prep(prep, s));
     const bool big = e->log2n > 14;
     const uint32_t hpw = e->par.hops_per_window;
     const size_t per_hop = (size_t)N * (devk ? 28 : 12);  // spectrum(s) / quarter-FFT scratch, y

@@ -176,6 +176,18 @@ hipError_t launch_dev_kernel(const DevKernelParams &p, hipStream_t s);
 //   stage 1: Z[k] = |X[k]| e^{i theta(seed, c, hop, k)}                 (in place)
 //   stage 2: y[n] = Re(sum_k Z[k] e^{+2 pi i n k / N}) / N * w[n]       -> p.ybuf
 // followed by the gather-form overlap-add (launch_ola).
+// One small launch in front of a job: the zero-padded copy of the input tail that the hops past the end of the
+// input read (src/stretcher.rs:129-132) and the reset of the run counter of the seam hand-over.
+struct PrepParams {
+    float *xtail;         // [n_channels][tail_len] or nullptr (no hop of the job runs past the input)
+    size_t tail_len;
+    const float *src;     // first sample of the tail, channel 0
+    size_t src_stride;
+    size_t real;          // samples that exist (the rest is zero)
+    uint32_t n_channels;
+    uint32_t *run_counter;  // or nullptr
+};
+hipError_t launch_prep(const PrepParams &p, hipStream_t s);
 hipError_t launch_gen(int stage, const HopParams &p, hipStream_t s);
 
 }  // namespace rc

@@ -3579,6 +3579,22 @@ hipError_t launch_gen(int stage, const HopParams &p, hipStream_t s) {
     return hipSuccess;
 }
 
+__global__ __launch_bounds__(256) void prep_kernel(const PrepParams q) {
+    if (q.run_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *q.run_counter = 0;
+    if (!q.xtail) return;
+    const uint32_t ch = blockIdx.y;
+    GF src = (GF)q.src + (size_t)ch * q.src_stride;
+    GFW dst = (GFW)q.xtail + (size_t)ch * q.tail_len;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < q.tail_len; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = i < q.real ? src[i] : 0.0f;
+}
+hipError_t launch_prep(const PrepParams &p, hipStream_t s) {
+    if (!p.xtail && !p.run_counter) return hipSuccess;
+    const unsigned bx = p.xtail ? (unsigned)std::min<size_t>(64, (p.tail_len + 255) / 256) : 1u;
+    hipLaunchKernelGGL(prep_kernel, dim3(bx, p.xtail ? p.n_channels : 1u), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only) {
     const dim3 grid((unsigned)p.hop_count, p.n_channels), block(256);
     if (!tail_only) {
