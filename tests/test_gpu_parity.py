@@ -835,6 +835,45 @@ def test_hop4_agrees_with_previous_kernel_generation(monkeypatch, p):
     assert rel <= 2e-7, rel
 
 
+def test_baseline_c1_full_size_every_sample():
+    """BASELINE C1 (the reference's own CPU-runnable case): mono, window 16384, factor 1, L = 2 646 000 —
+    322 hops, every output sample against the oracle."""
+    ra = _engine_mod()
+    N, f, L, seed = 16384, 1.0, 2_646_000, 0x5EED
+    x = onp.synth_input(0, L)[None, :]
+    got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=1, seed=seed)
+    ref = oc.stretch_offline(x, N, f, 1.0, 1, seed=seed)
+    assert got.shape == ref.shape == (1, 2_637_824)
+    assert_parity(got[0], ref[0], "C1")
+
+
+def test_big4_agrees_with_three_kernel_pipeline_at_c5_size(monkeypatch):
+    """BASELINE C5 at full size, every sample of all eight channels: the fused big4_kernel (one workgroup per
+    run of hops, tail through its per-workgroup scratch) against the three-kernel pipeline through HBM scratch
+    that computed C5 in round 1 (kept behind ROCODER_DIAG=2). Different FFT factorisations, same bins, same
+    phases: they must agree far inside the tolerance at every run / scratch position of the full-size job."""
+    import torch
+
+    ra = _engine_mod()
+    N, f, L, seed, C = 65536, 32.0, 5_292_000, 0x5EED, 8
+    xt = torch.from_numpy(np.stack([onp.synth_input(c, L) for c in range(C)])).cuda()
+    with ra.Engine(window_len=N, factor=f, channels=C, seed=seed) as e:
+        new = e.stretch_tensor(xt).clone()
+        torch.cuda.synchronize()
+    monkeypatch.setenv("ROCODER_DIAG", "2")
+    with ra.Engine(window_len=N, factor=f, channels=C, seed=seed) as e:
+        old = e.stretch_tensor(xt).clone()
+        torch.cuda.synchronize()
+    assert new.shape == old.shape == (C, 167_313_408)
+    assert torch.isfinite(new).all()
+    for c in range(C):
+        d = new[c].double() - old[c].double()
+        ref_rms = float(old[c].double().pow(2).mean().sqrt())
+        assert ref_rms > 0.01
+        assert float(d.pow(2).mean().sqrt()) <= 4e-6 * ref_rms, c
+        assert float(d.abs().max()) <= 1e-4, c
+
+
 def test_seam_wait_expiry_fails_loudly(monkeypatch):
     """The run-seam hand-over of the N = 16384 kernel has a bounded wait. With the diagnostic flag that
     makes producers skip the publish (ROCODER_DIAG=1), consumers must give up, leave a device error
