@@ -6,6 +6,7 @@
 #include "rc_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -213,6 +214,14 @@ struct rc_engine {
         hipEvent_t ev_fwd[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
         hipEvent_t ev_in = nullptr, ev_done = nullptr;
     } kp;
+    // host-buffer calls (rc_engine_stretch_host): pinned staging slots, one per copy worker (host_copy)
+    struct HostPipe {
+        static constexpr int kWorkers = 8;
+        static constexpr size_t kSlotBytes = (size_t)16 << 20;
+        void *slot[kWorkers] = {};
+        hipStream_t st[kWorkers] = {};
+        hipEvent_t ev_start = nullptr;
+    } hp;
 };
 
 namespace {
@@ -1156,6 +1165,11 @@ void rc_engine_destroy(rc_engine *e) {
         if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]);
         if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]);
     }
+    for (int i = 0; i < rc_engine::HostPipe::kWorkers; ++i) {
+        if (e->hp.slot[i]) (void)hipHostFree(e->hp.slot[i]);
+        if (e->hp.st[i]) (void)hipStreamDestroy(e->hp.st[i]);
+    }
+    if (e->hp.ev_start) (void)hipEventDestroy(e->hp.ev_start);
     if (e->ev_last) (void)hipEventDestroy(e->ev_last);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->h_err) (void)hipHostFree(e->h_err);
@@ -1315,6 +1329,69 @@ int rc_engine_stretch_device(rc_engine *e, const float *d_in, size_t in_stride, 
     return rc_catch();
 }
 
+namespace {
+// Host <-> device copies of a host-buffer call. Pageable memory cannot be the target of a DMA, so the runtime's own
+// hipMemcpyAsync stages it on one thread (measured 14 GB/s on 1.7 GB of output). Here up to eight workers each own a
+// 16 MiB pinned slot and a stream: DMA into / out of the slot, memcpy between slot and the caller's buffer; the
+// workers' DMAs and memcpys overlap each other. `to_device`: rows host[c][0..n) -> dev + c * dev_stride, else the
+// reverse. D2H starts after everything enqueued on e->stream so far; on return all copies are complete.
+int host_copy(rc_engine *e, bool to_device, float *const *host, float *dev, size_t dev_stride, size_t n, uint32_t C) {
+    using HP = rc_engine::HostPipe;
+    const size_t total = (size_t)C * n * sizeof(float);
+    if (total == 0) return RC_OK;
+    const size_t slot_floats = HP::kSlotBytes / sizeof(float);
+    const size_t per_row = (n + slot_floats - 1) / slot_floats, n_chunks = per_row * C;
+    int workers = (int)std::min<size_t>(HP::kWorkers, n_chunks);
+    workers = std::max(1, std::min<int>(workers, (int)std::max(1u, std::thread::hardware_concurrency())));
+    if (total < ((size_t)4 << 20)) {  // small: the plain path (no threads)
+        for (uint32_t c = 0; c < C; ++c) {
+            if (to_device) RC_HIP(hipMemcpyAsync(dev + (size_t)c * dev_stride, host[c], n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+            else RC_HIP(hipMemcpyAsync(host[c], dev + (size_t)c * dev_stride, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        }
+        if (!to_device) RC_HIP(hipStreamSynchronize(e->stream));
+        return RC_OK;
+    }
+    for (int w = 0; w < workers; ++w) {
+        if (!e->hp.slot[w]) RC_HIP(hipHostMalloc(&e->hp.slot[w], HP::kSlotBytes, hipHostMallocDefault));
+        if (!e->hp.st[w]) RC_HIP(hipStreamCreateWithFlags(&e->hp.st[w], hipStreamNonBlocking));
+    }
+    if (!e->hp.ev_start) RC_HIP(hipEventCreateWithFlags(&e->hp.ev_start, hipEventDisableTiming));
+    // the workers' streams start behind what the engine's stream holds (the compute of a D2H; earlier users of d_in)
+    RC_HIP(hipEventRecord(e->hp.ev_start, e->stream));
+    for (int w = 0; w < workers; ++w) RC_HIP(hipStreamWaitEvent(e->hp.st[w], e->hp.ev_start, 0));
+    std::atomic<size_t> next{0};
+    std::atomic<int> err{0};
+    auto work = [&](int w) {
+        if (hipSetDevice(e->device) != hipSuccess) { err = 1; return; }
+        float *slot = (float *)e->hp.slot[w];
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n_chunks || err.load()) return;
+            const uint32_t c = (uint32_t)(i / per_row);
+            const size_t off = (i % per_row) * slot_floats, cnt = std::min(slot_floats, n - off);
+            float *d = dev + (size_t)c * dev_stride + off;
+            float *h = host[c] + off;
+            if (to_device) {
+                std::memcpy(slot, h, cnt * sizeof(float));
+                if (hipMemcpyAsync(d, slot, cnt * sizeof(float), hipMemcpyHostToDevice, e->hp.st[w]) != hipSuccess ||
+                    hipStreamSynchronize(e->hp.st[w]) != hipSuccess) { err = 1; return; }
+            } else {
+                if (hipMemcpyAsync(slot, d, cnt * sizeof(float), hipMemcpyDeviceToHost, e->hp.st[w]) != hipSuccess ||
+                    hipStreamSynchronize(e->hp.st[w]) != hipSuccess) { err = 1; return; }
+                std::memcpy(h, slot, cnt * sizeof(float));
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < workers; ++w) th.emplace_back(work, w);
+    work(0);
+    for (auto &t : th) t.join();
+    if (err.load()) return fail(RC_EHIP, "host copy: %s", hipGetErrorString(hipGetLastError()));
+    // (H2D: every worker synchronised its stream, so whatever is launched on e->stream next sees the data)
+    return RC_OK;
+}
+}  // namespace
+
 int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, float *const *out,
                            size_t out_cap, size_t *out_len) try {
     if (!e || !in || !out) return fail(RC_EINVAL, "null argument");
@@ -1328,16 +1405,11 @@ int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, 
     const size_t in_stride = std::max<size_t>(in_len, 1);
     if ((rc = e->d_in.reserve((size_t)C * in_stride * sizeof(float)))) return rc;
     if ((rc = e->d_out.reserve((size_t)C * std::max<size_t>(n_out, 1) * sizeof(float)))) return rc;
-    for (uint32_t c = 0; c < C; ++c)
-        if (in_len)
-            RC_HIP(hipMemcpyAsync((float *)e->d_in.p + (size_t)c * in_stride, in[c], in_len * sizeof(float),
-                                  hipMemcpyHostToDevice, e->stream));
+    if ((rc = host_copy(e, true, const_cast<float *const *>(in), (float *)e->d_in.p, in_stride, in_len, C))) return rc;
     rc = rc_engine_stretch_device_range(e, (const float *)e->d_in.p, in_stride, in_len, 0, C, 0, total_win,
                                         (float *)e->d_out.p, n_out, n_out, e->stream);
     if (rc) return rc;
-    for (uint32_t c = 0; c < C; ++c)
-        RC_HIP(hipMemcpyAsync(out[c], (float *)e->d_out.p + (size_t)c * n_out, n_out * sizeof(float),
-                              hipMemcpyDeviceToHost, e->stream));
+    if ((rc = host_copy(e, false, out, (float *)e->d_out.p, n_out, n_out, C))) return rc;
     RC_HIP(hipStreamSynchronize(e->stream));
     if ((rc = check_device_error(e))) return rc;
     if (out_len) *out_len = n_out;
