@@ -155,7 +155,11 @@ struct Channel {
     uint64_t next_window = 0;  // next window index to COMPUTE
     uint64_t windows_out = 0;  // windows handed to the caller
     int64_t done_window = -1;  // window index whose hand-out sets is_done
-    std::deque<std::vector<float>> ready;
+    // computed windows not handed out yet: one pinned block per channel (the D2H lands here at link speed and
+    // next_window copies one window out of it), windows [ready_pos, ready_n) are pending
+    float *ready_p = nullptr;
+    size_t ready_cap = 0;      // floats
+    uint64_t ready_pos = 0, ready_n = 0;
 };
 
 }  // namespace
@@ -193,7 +197,7 @@ struct rc_engine {
     // code here; the next API call reports it as RC_EHIP
     uint32_t *h_err = nullptr, *d_err = nullptr;
     uint32_t diag_flags = 0;  // ROCODER_DIAG (tests only)
-    std::vector<float> h_spec, h_spec2, h_io;
+    std::vector<float> h_spec, h_spec2;
     bool tail_zeroed = false;
     // user-kernel path: a stateful apply() forbids recomputing hops, so the overlap tail is carried
     // on the device and ranges must continue where the previous one ended (or restart at hop 0)
@@ -1165,6 +1169,8 @@ void rc_engine_destroy(rc_engine *e) {
         if (e->ev0[i]) (void)hipEventDestroy(e->ev0[i]);
         if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]);
     }
+    for (auto &c : e->ch)
+        if (c.ready_p) (void)hipHostFree(c.ready_p);
     for (int i = 0; i < rc_engine::HostPipe::kWorkers; ++i) {
         if (e->hp.slot[i]) (void)hipHostFree(e->hp.slot[i]);
         if (e->hp.st[i]) (void)hipStreamDestroy(e->hp.st[i]);
@@ -1221,7 +1227,7 @@ int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out
     const uint32_t N = P.window_len, hpw = P.hops_per_window, step = P.sample_step_len;
     const uint32_t wout = P.window_out_len;
     if (out_cap < wout) return fail(RC_ECAPACITY, "out_cap %zu < window_out_len %u", out_cap, wout);
-    if (c.ready.empty()) {
+    if (c.ready_pos == c.ready_n) {
         // how many whole windows can be computed now?
         //  hop h needs samples [h*step, h*step+N); on a closed channel the shortfall is zero
         //  padded and `done` is raised at the first short hop (src/stretcher.rs:123-135).
@@ -1249,6 +1255,8 @@ int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out
         // channels (src/stretcher_processor.rs:63-70: windows outer, channels inner) is also the order in
         // which apply() sees the hops
         if (e->cfg.kernel) max_win = 1;
+        // one batch fills at most 16 MiB of the channel's pinned block
+        max_win = std::min<uint64_t>(max_win, std::max<uint64_t>(1, (((size_t)16 << 20) / sizeof(float)) / wout));
         nwin = std::min<uint64_t>(nwin, max_win);
         const uint64_t hop_count = nwin * hpw;
         // input span: from the hop before k0 (its tail is recomputed) unless a user kernel
@@ -1268,26 +1276,34 @@ int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out
                       (int64_t)k0, (int64_t)hop_count, (float *)e->d_out.p, 0,
                       (int64_t)(c.next_window * wout), e->stream, false);
         if (rc) return rc;
-        e->h_io.resize((size_t)nwin * wout);
-        RC_HIP(hipMemcpyAsync(e->h_io.data(), e->d_out.p, (size_t)nwin * wout * sizeof(float),
-                              hipMemcpyDeviceToHost, e->stream));
+        if (c.ready_cap < (size_t)nwin * wout) {
+            if (c.ready_p) RC_HIP(hipHostFree(c.ready_p));
+            c.ready_p = nullptr;
+            c.ready_cap = 0;
+            RC_HIP(hipHostMalloc((void **)&c.ready_p, (size_t)nwin * wout * sizeof(float), hipHostMallocDefault));
+            c.ready_cap = (size_t)nwin * wout;
+        }
+        RC_HIP(hipMemcpyAsync(c.ready_p, e->d_out.p, (size_t)nwin * wout * sizeof(float), hipMemcpyDeviceToHost,
+                              e->stream));
         RC_HIP(hipStreamSynchronize(e->stream));
         if ((rc = check_device_error(e))) return rc;
-        for (uint64_t w = 0; w < nwin; ++w)
-            c.ready.emplace_back(e->h_io.begin() + w * wout, e->h_io.begin() + (w + 1) * wout);
+        c.ready_pos = 0;
+        c.ready_n = nwin;
         c.next_window += nwin;
-        // drop input no later hop needs: keep from (next hop - 1) * step
+        // drop input no later hop needs (keep from (next hop - 1) * step) once it is at least half of what is
+        // held: erasing the front of the vector every batch would move the whole remainder each time
         const uint64_t keep_from = (c.next_window * hpw > 0 ? c.next_window * hpw - 1 : 0) * (uint64_t)step;
         if (keep_from > c.fifo_base) {
             const uint64_t drop = std::min<uint64_t>(keep_from - c.fifo_base, c.fifo.size());
-            c.fifo.erase(c.fifo.begin(), c.fifo.begin() + drop);
-            c.fifo_base += drop;
+            if (drop * 2 >= c.fifo.size()) {
+                c.fifo.erase(c.fifo.begin(), c.fifo.begin() + drop);
+                c.fifo_base += drop;
+            }
         }
     }
-    std::vector<float> &w = c.ready.front();
-    memcpy(out, w.data(), w.size() * sizeof(float));
-    if (n_out) *n_out = w.size();
-    c.ready.pop_front();
+    memcpy(out, c.ready_p + (size_t)c.ready_pos * wout, (size_t)wout * sizeof(float));
+    if (n_out) *n_out = wout;
+    c.ready_pos++;
     c.windows_out++;
     return RC_OK;
 } catch (...) {
