@@ -368,6 +368,8 @@ struct KernelStack {
     }
 };
 
+static bool g_timing = false;  // ROCODER_CLI_TIMING
+
 // ------------------------------------------------------------------ src/stretcher.rs over the engine
 struct Engine {
     rc_engine *h = nullptr;
@@ -406,6 +408,11 @@ struct Stretcher {
             if (!input.empty()) {
                 rc_engine_push_input(eng->h, channel, input.front().data(), input.front().size());
                 input.pop_front();
+                // file input: main queued the whole channel and dropped its sender before the processor started
+                // (main.rs:148-150), so an empty queue IS the disconnect. Telling the engine now instead of at the
+                // next shortfall lets it batch ahead (an open channel is computed one queue-bound at a time);
+                // the windows are the same either way
+                if (input.empty() && input_closed) rc_engine_close_input(eng->h, channel);
             } else {
                 rc_engine_close_input(eng->h, channel);  // Err(_): Sender dropped, stretcher.rs:129-132
             }
@@ -419,10 +426,15 @@ struct StretcherProcessor {
     std::atomic<bool> shutdown{false}, finished{false};
     std::thread th;
     std::string error;
-    std::vector<std::shared_ptr<WindowQueue>> make(std::vector<Stretcher> st) {
+    double t_next = 0, t_send = 0;
+    // min_depth: file-to-file runs deepen the queues (the results do not depend on the depth). The reference's
+    // bound is ceil(window seconds / buffer seconds) = 1 at the defaults: two thread hand-offs per window, which
+    // its ~1 ms of CPU work per window hides and the engine's ~1 us per window does not (2.0 of 2.3 s on a
+    // 600 s stereo file)
+    std::vector<std::shared_ptr<WindowQueue>> make(std::vector<Stretcher> st, size_t min_depth = 1) {
         std::vector<std::shared_ptr<WindowQueue>> rx;
         for (auto &s : st) {
-            auto q = std::make_shared<WindowQueue>(s.channel_bound());  // bounded(channel_bound())
+            auto q = std::make_shared<WindowQueue>(std::max(s.channel_bound(), min_depth));  // bounded(channel_bound())
             rx.push_back(q);
             channels.emplace_back(q, std::move(s));
         }
@@ -440,12 +452,23 @@ struct StretcherProcessor {
                             running = false;
                             break;
                         }
-                        c.first->send(c.second.next_window());  // :69
+                        if (!g_timing) {
+                            c.first->send(c.second.next_window());  // :69
+                        } else {  // ROCODER_CLI_TIMING: where the processor thread's time goes
+                            const auto t0 = std::chrono::steady_clock::now();
+                            auto w = c.second.next_window();
+                            const auto t1 = std::chrono::steady_clock::now();
+                            c.first->send(std::move(w));
+                            const auto t2 = std::chrono::steady_clock::now();
+                            t_next += std::chrono::duration<double, std::milli>(t1 - t0).count();
+                            t_send += std::chrono::duration<double, std::milli>(t2 - t1).count();
+                        }
                     }
                 }
             } catch (const std::exception &ex) {
                 error = ex.what();
             }
+            if (g_timing) fprintf(stderr, "[timing] processor: next_window %.1f ms, send %.1f ms\n", t_next, t_send);
             for (auto &c : channels) c.first->close();
             finished.store(true);  // :72
         });
@@ -456,10 +479,11 @@ struct StretcherProcessor {
 };
 
 // AudioBus::into_audio (src/audio.rs:152-172): 5 ms recv_timeout polling drain
-Audio into_audio(const AudioSpec &spec, std::vector<std::shared_ptr<WindowQueue>> &chs) {
+Audio into_audio(const AudioSpec &spec, std::vector<std::shared_ptr<WindowQueue>> &chs, size_t expected = 0) {
     Audio a;
     a.spec = spec;
     a.data.assign(chs.size(), {});
+    for (auto &c : a.data) c.reserve(expected);
     std::vector<bool> closed(chs.size(), false);
     for (;;) {
         size_t disconnected = 0;
@@ -573,6 +597,15 @@ int run(int argc, char **argv) {
     if (!o.output) throw std::runtime_error("live playback (no -o) is not supported: pass -o <file.wav>");
     if (o.pitch_multiple < -128 || o.pitch_multiple > 127) throw std::runtime_error("pitch_multiple must fit an i8");
 
+    // ROCODER_CLI_TIMING=1: wall time of each phase on stderr (dev aid)
+    const bool timing = g_timing = getenv("ROCODER_CLI_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[timing] %-14s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     // load_audio (src/main.rs:162-188)
     FILE *f = *o.input == "-" ? stdin : fopen(o.input->c_str(), "rb");
     if (!f) throw std::runtime_error("cannot open " + *o.input);
@@ -582,6 +615,7 @@ int run(int argc, char **argv) {
     if (o.rotate_channels) audio.rotate_channels();
     const size_t total_samples_len = audio.data.empty() ? 0 : audio.data[0].size();
     const AudioSpec spec = audio.spec;
+    lap("read input");
 
     KernelStack kernels;
     if (o.freq_kernel) kernels.start(*o.freq_kernel);
@@ -627,6 +661,7 @@ int run(int argc, char **argv) {
     }
     auto eng = std::make_shared<Engine>();
     if (rc_engine_create(&cfg, &eng->h) != RC_OK) throw std::runtime_error(std::string("rocoder_hip: ") + rc_last_error());
+    lap("engine create");
 
     // one Stretcher per channel, fed the whole channel as one chunk (src/main.rs:133-153)
     std::vector<Stretcher> stretchers;
@@ -637,18 +672,20 @@ int run(int argc, char **argv) {
         s.channel = c;
         rc_engine_get_params(eng->h, &s.par);
         s.input.push_back(std::move(audio.data[c]));
+        s.input_closed = true;  // nothing else will be sent
         stretchers.push_back(std::move(s));
     }
     const size_t expected_total_samples = (size_t)((float)total_samples_len * o.factor);  // main.rs:154
-    (void)expected_total_samples;
     StretcherProcessor proc;
-    auto bus = proc.make(std::move(stretchers));
+    auto bus = proc.make(std::move(stretchers), 64);
     proc.start();
     // handle_result (src/main.rs:190-211)
-    Audio out = into_audio(spec, bus);
+    Audio out = into_audio(spec, bus, expected_total_samples + o.window_len);
     proc.join();
     if (!proc.error.empty()) throw std::runtime_error(proc.error);
+    lap("stretch");
     write_wav_f32(*o.output, out);
+    lap("write output");
     return 0;
 }
 
