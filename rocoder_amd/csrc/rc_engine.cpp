@@ -656,12 +656,15 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
 #endif
     if (RC_BIG4 && e->log2n > 14 && !e->cfg.kernel && !devk && e->cfg.pitch_multiple >= 1 &&
         !(e->diag_flags & rc::RC_DIAG_PREV_KERNEL)) {
-        // fused large-window kernel: one workgroup (512 threads, ~150 KB of LDS: one per CU) per run of hops,
-        // about three rounds of workgroups per launch; each run recomputes the hop before it for its tail
+        // fused large-window kernel: one workgroup (512 threads, ~150 KB of LDS: one per CU) per run of hops;
+        // each run recomputes the hop before it for its tail
         p.hop_first = hop_first;
         p.hop_count = hop_count;
         p.wtab = e->d_wtab_m;
-        uint64_t r = std::max<uint64_t>(1, (uint64_t)e->n_cu * 3 / n_channels);
+        // one workgroup per CU and launch (measured on C5: 1 / 2 / 3 / 4 / 6 rounds of workgroups = 6.45 / 6.50 / 6.61 /
+        // 6.60 / 6.72 ms: every run recomputes one hop and reloads its tables); ROCODER_B4_ROUNDS overrides (tuning)
+        static const int b4_rounds = getenv("ROCODER_B4_ROUNDS") ? std::max(1, atoi(getenv("ROCODER_B4_ROUNDS"))) : 1;
+        uint64_t r = std::max<uint64_t>(1, (uint64_t)e->n_cu * b4_rounds / n_channels);
         r = std::max<uint64_t>(1, std::min<uint64_t>(r, (uint64_t)hop_count / 8));
         const uint64_t len = ((uint64_t)hop_count + r - 1) / r;
         p.run_len = (uint32_t)len;
