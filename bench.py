@@ -9,7 +9,9 @@ range) shards, one rank per GPU (N = 2: a channel per GPU; N = 4, 8: half / quar
 rank recomputes the single hop before its range): per-GPU work is that of N = 1 (weak scaling) and the
 data path has no collective. `value` = output samples of all ranks / max-rank time of the timed steps,
 outputs left sharded in HBM; the cost of the one optional collective, the RCCL concat of the shards on
-rank 0, is measured in a second timed region and reported beside it (config.concat).
+rank 0, is measured in a second timed region and reported beside it (config.concat); at N > 1 BASELINE
+configs[4] (C5: 8 channels, window 65536) cut over the same ranks is timed as well (config.c5_sharded). Both
+extras run after the main line is complete, under a watchdog, so they can never cost the measurement.
 
 The same JSON line carries
   roofline     — the dominant kernel (the N = 16384 fused hop kernel) priced on SURVEY §8(d4)'s
@@ -362,13 +364,15 @@ def main():
             if rank == 0 and not emitted[0]:
                 if concat:
                     res["config"]["concat"] = concat
+                if c5:
+                    res["config"]["c5_sharded"] = c5
                 os.write(real_stdout, (json.dumps(res) + "\n").encode())
             emitted[0] = True
 
     def watchdog():
         nonlocal concat
         if not emitted[0]:
-            concat = {"error": f"concat region did not finish within {CONCAT_TIMEOUT_S} s; the main line is unaffected"}
+            concat = {"error": f"the post-measurement extras (C5 shards, concat) did not finish within {CONCAT_TIMEOUT_S} s; the main line is unaffected"}
         emit()
         os._exit(0)
 
@@ -376,6 +380,48 @@ def main():
     timer.daemon = True
     if world > 1:
         timer.start()
+    c5 = None
+    if not args.no_extras and dist is not None and world > 1:
+        # BASELINE configs[4] (C5: 8 channels, window 65536, factor 32, L = 5 292 000 per channel) cut over the
+        # ranks by the same shard_plan (8 ranks: one channel per GPU, no halo). Not the metric's config: it rides in
+        # config.c5_sharded, measured after the main line is complete.
+        try:
+            with torch.cuda.stream(stream):
+                C5 = dict(window=65536, factor=32.0, channels=8, length=5_292_000)
+                eng5 = rocoder_amd.Engine(window_len=C5["window"], factor=C5["factor"], pitch_multiple=1,
+                                          sample_rate=SAMPLE_RATE, channels=C5["channels"], seed=SEED, device=dev_index)
+                x5 = synth_on_device(torch, device, C5["channels"], C5["length"])
+                wout5 = eng5.params.window_out_len
+                n_out5 = eng5.output_len(C5["length"])
+                nwin5 = n_out5 // wout5
+                plan5 = shard_plan(C5["channels"], nwin5, world)
+                mine5 = [s for s in plan5 if s.rank == rank]
+                comp5 = engine_compute(eng5, x5)
+                bufs5 = {s: torch.empty((s.ch_count, s.win_count * wout5), dtype=torch.float32, device=device)
+                         for s in mine5}
+                for _ in range(3):
+                    for s in mine5:
+                        comp5(s, out=bufs5[s])
+                barrier()
+                k5 = max(3, min(10, args.steps))
+                t5 = time.perf_counter()
+                for _ in range(k5):
+                    for s in mine5:
+                        comp5(s, out=bufs5[s])
+                barrier()
+                dt5 = max_over_ranks(time.perf_counter() - t5)
+                c5 = {
+                    "workload": "BASELINE configs[4]: 8 ch, window=65536, factor=32, L=5292000/ch, one job cut by shard_plan",
+                    "steps": k5,
+                    "ms_per_step": round(dt5 / k5 * 1e3, 4),
+                    "value_Msamples_s": round(float(n_out5) * C5["channels"] * k5 / dt5 / 1e6, 1),
+                    "plan": [(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan5],
+                }
+                del bufs5, x5
+                eng5.close()
+        except Exception as ex:  # noqa: BLE001
+            c5 = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        note(f"c5 extra: {c5}")
     if not args.no_extras:
         with torch.cuda.stream(stream):
             if dist is not None and world > 1 and rehearsal:
