@@ -2860,6 +2860,14 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
         if (RC_B4_LGKM) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
         else __syncthreads();                                                            \
     } while (0)
+#ifndef RC_B4_TAILNT
+#define RC_B4_TAILNT 0  // 1: non-temporal tail-scratch accesses (experiment)
+#endif
+__device__ __forceinline__ v2f tail_ld(GV2 p) { return RC_B4_TAILNT ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void tail_st(GV2W p, v2f v) {
+    if (RC_B4_TAILNT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 #ifndef RC_B4_ABL
 #define RC_B4_ABL 0  // timing-only ablations of big4_kernel: 1 no input loads, 2 no tail scratch traffic, 4 no output stores
 #endif
@@ -3179,7 +3187,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         v2f tpre[TPRE ? PH : 1];
         if constexpr (TPRE) {
 #pragma unroll
-            for (int q = 0; q < PH; ++q) tpre[q] = to_v(ldg2((GV2)tsc + T * q + (unsigned)tt));
+            for (int q = 0; q < PH; ++q) tpre[q] = tail_ld((GV2)tsc + T * q + (unsigned)tt);
         }
         dit_g<R, 9, m - 1, 9, true, true>(y, to_v(lds[T_A + tid]));
         stp.mark(9);
@@ -3211,7 +3219,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             if constexpr (TPIPE) {
 #pragma unroll
                 for (int q = 0; q < EB; ++q)
-                    tnx[q] = (RC_B4_ABL & 2) ? v2f{0.f, 0.f} : to_v(ldg2((GV2)tsc + T * q + (unsigned)tt));
+                    tnx[q] = (RC_B4_ABL & 2) ? v2f{0.f, 0.f} : tail_ld((GV2)tsc + T * q + (unsigned)tt);
             }
 #pragma unroll
             for (int q0 = 0; q0 < PH; q0 += EB) {
@@ -3223,7 +3231,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                     if (q0 + EB < PH) {
 #pragma unroll
                         for (int q = 0; q < EB; ++q)
-                            tnx[q] = (RC_B4_ABL & 2) ? v2f{0.f, 0.f} : to_v(ldg2((GV2)tsc + T * (q0 + EB + q) + (unsigned)tt));
+                            tnx[q] = (RC_B4_ABL & 2) ? v2f{0.f, 0.f} : tail_ld((GV2)tsc + T * (q0 + EB + q) + (unsigned)tt);
                     }
                 }
 #pragma unroll
@@ -3266,7 +3274,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                         }
                     }
                     if constexpr (TAIL_GLOBAL) {
-                        if (!(RC_B4_ABL & 2)) stg2(tsc + T * (q0 + q) + (unsigned)tt, to_f2(nt));
+                        if (!(RC_B4_ABL & 2)) tail_st(tsc + T * (q0 + q) + (unsigned)tt, nt);
                         else if (nt.x == 1.2345f) stg2(tsc, to_f2(nt));  // (keeps nt alive)
                     }
                     else tail[q0 + q] = nt;
