@@ -252,14 +252,22 @@ void plan_runs(const rc_engine *e, uint32_t n_channels, int64_t hop_count, uint3
     uint32_t rounds = RC_ROUNDS;
     if (const int fixed = rc::hop_workgroups_per_cu(e->log2n, e->d_hann_rot != nullptr)) {  // (N = 16384 only)
         wg_per_cu = (uint32_t)fixed;
-        rounds = 2 * RC_ROUNDS;  // measured: 4 rounds of 768 workgroups beat 2 (tail balance) and 6
+        // 8 rounds of 768 workgroups = runs of 9 hops at C2. With hop4's per-XCD run tickets the 96 runs resident on
+        // an XCD are neighbours, 9 hops = 36 KB apart, so their 64 KB windows overlap and the XCD's working set (3.5 MB)
+        // fits its L2: FETCH_SIZE 1.12e6 -> 0.44e6 KiB per launch, L2 hit rate 42 -> 61 %, and in an interleaved A/B
+        // (tools/ab_rounds.py) 4 / 6 / 8 / 12 rounds = 1.434 / 1.422 / 1.423 / 1.421 ms; shorter runs (min_run 4) lose
+        // to the seam hand-overs again
+        rounds = 4 * RC_ROUNDS;
+        const int env_rounds = getenv("ROCODER_ROUNDS") ? atoi(getenv("ROCODER_ROUNDS")) : 0;  // tuning
+        if (env_rounds > 0) rounds = (uint32_t)env_rounds;
     }
 #ifdef RC_WG_PER_CU
     wg_per_cu = RC_WG_PER_CU;  // tuning builds
 #endif
     const uint64_t target = (uint64_t)e->n_cu * wg_per_cu * rounds;  // rounds of resident workgroups
     uint64_t r = std::max<uint64_t>(1, target / std::max<uint32_t>(1, n_channels));
-    const int64_t min_run = 8;
+    const int env_min_run = getenv("ROCODER_MIN_RUN") ? atoi(getenv("ROCODER_MIN_RUN")) : 0;  // tuning
+    const int64_t min_run = env_min_run > 0 ? env_min_run : 8;
     r = std::min<uint64_t>(r, (uint64_t)std::max<int64_t>(1, hop_count / min_run));
     r = std::max<uint64_t>(r, 1);
     uint64_t len = ((uint64_t)hop_count + r - 1) / r;
@@ -621,7 +629,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
             const size_t flag_cap = e->d_seam_flag.cap;
             if (e->d_seam_head.reserve(runs_total * H * sizeof(float)) == RC_OK &&
                 e->d_seam_flag.reserve(runs_total * sizeof(uint32_t)) == RC_OK &&
-                e->d_run_counter.reserve(sizeof(uint32_t)) == RC_OK) {
+                e->d_run_counter.reserve(rc::RC_RUN_COUNTERS * sizeof(uint32_t)) == RC_OK) {
                 if (e->d_seam_flag.cap != flag_cap) {  // fresh allocation: no flag equals any epoch yet
                     RC_HIP(hipMemsetAsync(e->d_seam_flag.p, 0, e->d_seam_flag.cap, s));
                     e->seam_epoch = 0;

@@ -46,7 +46,7 @@ struct HopParams {
     // workgroup that started after it and is already resident or next in line.
     float *seam_head;
     uint32_t *seam_flag;
-    uint32_t *run_counter;
+    uint32_t *run_counter;  // RC_RUN_COUNTERS words: hop4_kernel keeps one ticket counter per XCD
     uint32_t seam_epoch;
     // A run that never sees its successor's flag within seam_spin_limit polls gives up, leaves its seam
     // samples unwritten and reports through *err_word (host-visible pinned memory; RC_ERR_SEAM_TIMEOUT):
@@ -125,7 +125,7 @@ struct BigOlaParams {
 };
 
 // kernel generation (rc_kernel_id): bump whenever a change to the kernels can move a measurement
-#define RC_KERNEL_ID "hop4+big4/r02f"
+#define RC_KERNEL_ID "hop4+big4/r02g"
 
 enum HopMode { MODE_FUSED = 0, MODE_FORWARD = 1, MODE_RESYNTH = 2 };
 // values a kernel may leave in *HopParams::err_word
@@ -178,6 +178,7 @@ hipError_t launch_dev_kernel(const DevKernelParams &p, hipStream_t s);
 // followed by the gather-form overlap-add (launch_ola).
 // One small launch in front of a job: the zero-padded copy of the input tail that the hops past the end of the
 // input read (src/stretcher.rs:129-132) and the reset of the run counter of the seam hand-over.
+constexpr int RC_RUN_COUNTERS = 8;
 struct PrepParams {
     float *xtail;         // [n_channels][tail_len] or nullptr (no hop of the job runs past the input)
     size_t tail_len;
@@ -185,7 +186,7 @@ struct PrepParams {
     size_t src_stride;
     size_t real;          // samples that exist (the rest is zero)
     uint32_t n_channels;
-    uint32_t *run_counter;  // or nullptr
+    uint32_t *run_counter;  // RC_RUN_COUNTERS words, or nullptr
 };
 hipError_t launch_prep(const PrepParams &p, hipStream_t s);
 hipError_t launch_gen(int stage, const HopParams &p, hipStream_t s);

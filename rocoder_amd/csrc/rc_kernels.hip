@@ -1906,6 +1906,9 @@ __device__ __forceinline__ void wave_fence() {
 #define RC_DEFER_STORE 0
 #endif
 #define HOP4_PAIR pair_regs_pk4
+#ifndef RC_XCD_RUNS
+#define RC_XCD_RUNS 1
+#endif
 #define HOP4_BAR()                                                                    \
     do {                                                                              \
         if (RC_ABLATE & 32) break;                                                    \
@@ -1928,11 +1931,37 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
     uint32_t gr = blockIdx.x;
     const bool seam = p.seam_head != nullptr;
     if (seam) {
+        // Runs are handed out in the order workgroups start, per XCD: XCD x walks the x-th eighth of the runs
+        // (neighbouring runs read overlapping input and meet in one L2; a run waits at its end for the head its
+        // successor stashed at its start: the successor is the next ticket of the same XCD, or the first run of the
+        // next eighth, which started with the launch). An XCD that runs out takes from the next one's counter.
         unsigned *slot = reinterpret_cast<unsigned *>(lds + SCR);
-        if (tid == 0) *slot = atomicAdd(p.run_counter, 1u);
+        if (tid == 0) {
+            const uint32_t total = p.runs_per_channel * p.n_channels;
+            unsigned got = 0xFFFFFFFFu;
+            if (RC_XCD_RUNS) {
+                const uint32_t G = (total + 7u) / 8u;
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                for (uint32_t i = 0; i < 8u; ++i) {
+                    const uint32_t xx = (xcc + i) & 7u, lo = xx * G;
+                    if (lo >= total) continue;
+                    const uint32_t hi = lo + G < total ? lo + G : total;
+                    const uint32_t t = atomicAdd(p.run_counter + xx, 1u);
+                    if (t < hi - lo) {
+                        got = lo + t;
+                        break;
+                    }
+                }
+            } else {
+                got = atomicAdd(p.run_counter, 1u);
+            }
+            *slot = got;
+        }
         __syncthreads();
         gr = *reinterpret_cast<volatile unsigned *>(slot);
         __syncthreads();
+        if (gr == 0xFFFFFFFFu) return;  // (more workgroups than runs: cannot happen with the engine's grid)
     }
     const uint32_t run = gr % p.runs_per_channel;
     const uint32_t ch = gr / p.runs_per_channel;
@@ -3605,7 +3634,7 @@ hipError_t launch_gen(int stage, const HopParams &p, hipStream_t s) {
 }
 
 __global__ __launch_bounds__(256) void prep_kernel(const PrepParams q) {
-    if (q.run_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *q.run_counter = 0;
+    if (q.run_counter && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < RC_RUN_COUNTERS) q.run_counter[threadIdx.x] = 0;
     if (!q.xtail) return;
     const uint32_t ch = blockIdx.y;
     GF src = (GF)q.src + (size_t)ch * q.src_stride;
