@@ -236,6 +236,24 @@ def test_random_configurations_match_oracle():
     assert ran >= 35
 
 
+def test_many_channels_and_very_many_hops_match_oracle():
+    """Launch-geometry ends of the run planner: 13 channels through the N = 16384 kernel (channel count that
+    divides nothing: per-XCD run tickets, seams between runs of different channels), and 400 000 hops of a
+    256-sample window in one launch (hop indices and grids far beyond 16 bits) — every sample against the oracle."""
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, 190_000) for c in range(13)])
+    got = ra.stretch(x, window_len=16384, factor=8.0, seed=13)
+    ref = oc.stretch_offline(x, 16384, 8.0, 1.0, 1, seed=13)
+    assert got.shape == ref.shape
+    for c in range(13):
+        assert_parity(got[c], ref[c], f"13 channels, ch={c}")
+    x = onp.synth_input(3, 1_600_000)[None, :]
+    got = ra.stretch(x, window_len=256, factor=32.0, seed=14)   # step = 4 samples: 399 937 hops
+    ref = oc.stretch_offline(x, 256, 32.0, 1.0, 1, seed=14)
+    assert got.shape == ref.shape and got.shape[1] > 50_000_000
+    assert_parity(got[0], ref[0], "400k hops")
+
+
 # ------------------------------------------------------------------ user frequency kernel
 def test_gain_kernel_is_exactly_linear():
     # .norm() is linear: the x2.0 kernel config (BASELINE C4) must give 2 * F for the same phases
