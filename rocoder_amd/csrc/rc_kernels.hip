@@ -2080,16 +2080,25 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             GFW dst = outc + (kq - p.out_origin);
             int t2 = tid;
             opaque(t2);
+            // F[t] = O[t * pitch] (src/resampler.rs:3-18): sample a = kr + i of this hop is kept iff a % pitch == 0,
+            // at dst[a / pitch]. One division per hop and lane (q = 0); every further register pair is 2T = 512
+            // samples on: quotient and remainder advance by the uniform 512 / pitch and 512 % pitch
+            const uint32_t a00 = kr + 2u * (uint32_t)t2;
+            uint32_t d = a00 / pitch, r = a00 - d * pitch;
+            const uint32_t qs = (2u * T) / pitch, rs = (2u * T) - qs * pitch;
 #pragma unroll
             for (int q = 0; q < PH; ++q) {
-                const uint32_t i0 = 2u * (uint32_t)(t2 + T * q);
                 const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
                                __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
                 const v2f o = (head[q] + tail[q]) * er;
-                const uint32_t a0 = kr + i0, a1 = a0 + 1;
-                const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
-                if (d0 * pitch == a0) dst[d0] = o.x;
-                if (d1 * pitch == a1) dst[d1] = o.y;
+                if (r == 0) dst[d] = o.x;                 // a0 = d * pitch
+                if (r + 1 == pitch) dst[d + 1] = o.y;     // a1 = a0 + 1 = (d + 1) * pitch
+                d += qs;
+                r += rs;
+                if (r >= pitch) {
+                    r -= pitch;
+                    d += 1;
+                }
             }
         }
     };
