@@ -606,9 +606,23 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
             p.tail_hop_first = k_t;
         }
     }
-    // RC_DK_BAND / RC_DK_SHIFT act on the spectrum between analysis and resynthesis: unfused, but on the device
-    const bool devk = e->cfg.device_kernel == RC_DK_BAND || e->cfg.device_kernel == RC_DK_SHIFT;
+    // RC_DK_BAND / RC_DK_SHIFT act on the spectrum between analysis and resynthesis: unfused, but on the device —
+    // except the band mask on the default 16384-sample window, which hop4_kernel applies in its pair stage
+    // (a per-bin gain on the magnitudes: the fused kernel's speed instead of three kernels through HBM)
+    const bool band_fused = e->cfg.device_kernel == RC_DK_BAND && e->cfg.pitch_multiple >= 1 &&
+                            rc::hop_workgroups_per_cu(e->log2n, e->d_hann_rot != nullptr) != 0 &&
+                            !(e->diag_flags & rc::RC_DIAG_PREV_KERNEL);
+    const bool devk = (e->cfg.device_kernel == RC_DK_BAND && !band_fused) || e->cfg.device_kernel == RC_DK_SHIFT;
     const bool fused = !e->gen && !e->cfg.kernel && !devk && e->log2n <= 14 && e->cfg.pitch_multiple >= 1;
+    if (band_fused) {
+        const uint32_t half = e->par.window_len / 2;
+        const uint32_t lo = e->cfg.dk_lo_bin, hi = std::min<uint32_t>(e->cfg.dk_hi_bin, half);
+        p.band_on = 1;
+        p.band_lo = lo;
+        p.band_span = hi >= lo ? hi - lo : 0;
+        p.band_gout = fabsf(e->cfg.dk_gain_outside);
+        p.band_gin = hi >= lo ? fabsf(e->cfg.dk_gain) : p.band_gout;  // (an empty band: everything is outside)
+    }
     if (fused) {
         p.hop_first = hop_first;
         p.hop_count = hop_count;

@@ -48,6 +48,10 @@ struct HopParams {
     uint32_t *seam_flag;
     uint32_t *run_counter;  // RC_RUN_COUNTERS words: hop4_kernel keeps one ticket counter per XCD
     uint32_t seam_epoch;
+    // RC_DK_BAND fused into hop4_kernel's pair stage (band_on): bins lo..lo+span of the real spectrum (0..N/2) are
+    // scaled by band_gin, the others by band_gout (both already |.|: the resynthesis takes magnitudes)
+    uint32_t band_on, band_lo, band_span;
+    float band_gin, band_gout;
     // A run that never sees its successor's flag within seam_spin_limit polls gives up, leaves its seam
     // samples unwritten and reports through *err_word (host-visible pinned memory; RC_ERR_SEAM_TIMEOUT):
     // the engine turns that into RC_EHIP. diag_flags is test-only (RC_DIAG_*).

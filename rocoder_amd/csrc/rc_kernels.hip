@@ -1089,9 +1089,10 @@ __device__ __forceinline__ v2f cmulc_fma(v2f a, v2f w, v2f t) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
     return r;
 }
-template <int LOG2N, bool DC = false>
+// BAND: gq = the gains of bins ja and M - ja (the curated band-mask kernel RC_DK_BAND, fused: |g X| = |g| |X|)
+template <int LOG2N, bool DC = false, bool BAND = false>
 __device__ __forceinline__ void pair_regs_pk4(v2f A, v2f Bp, v2f w, uint32_t x1, PhaseKey key, v2f &VA,
-                                              v2f &VB, bool dc = false) {
+                                              v2f &VB, bool dc = false, v2f gq = v2f{1.0f, 1.0f}) {
     constexpr uint32_t N = 1u << LOG2N, M = N / 2;
     const uint32_t cM = M * key.mul + 2u * key.k0;
     const v2f cj = {1.0f, -1.0f}, jc = {-1.0f, 1.0f};
@@ -1101,7 +1102,8 @@ __device__ __forceinline__ void pair_regs_pk4(v2f A, v2f Bp, v2f w, uint32_t x1,
     const v2f U = __builtin_shufflevector(E, E, 0, 0) + __builtin_shufflevector(T, T, 1, 1) * cj;
     const v2f V = __builtin_shufflevector(E, E, 1, 1) + __builtin_shufflevector(T, T, 0, 0) * jc;
     const v2f q2 = __builtin_elementwise_fma(V, V, U * U);     // (|X1|^2, |X2c|^2)
-    const v2f mm = v2f{__builtin_amdgcn_sqrtf(q2.x), __builtin_amdgcn_sqrtf(q2.y)};
+    v2f mm = v2f{__builtin_amdgcn_sqrtf(q2.x), __builtin_amdgcn_sqrtf(q2.y)};
+    if constexpr (BAND) mm = mm * gq;
     v2f cs1, cs2, cs3, cs4;
     phase_cs2_x(x1, cs1, cs4);       // bins ja and M + ja
     phase_cs2_x(cM - x1, cs3, cs2);  // bins M - ja and N - ja
@@ -1915,7 +1917,11 @@ __device__ __forceinline__ void wave_fence() {
         if (RC_LGKM_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         else __syncthreads();                                                         \
     } while (0)
-template <bool PITCH1>
+// RC_DK_BAND fused into the pair stage: |gain| of real-spectrum bin f <= N/2 (lo <= f <= hi: inside)
+__device__ __forceinline__ float band_gain(const HopParams &p, uint32_t f) {
+    return (f - p.band_lo) <= p.band_span ? p.band_gin : p.band_gout;
+}
+template <bool PITCH1, bool BAND = false>
 __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
     constexpr int LOG2N = 14, m = 13, M = 1 << m, H = M, T = 256, P = 32, PH = 16;
     constexpr int RES = 512, REG = HOP4_REG;
@@ -2285,10 +2291,16 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
                 const v2f wq = q == 0 ? wrv : (q == 8 ? v2f{wr.y, -wr.x}
                                : vcmul(wrv, v2f{W32_RE[q & 15], W32_IM[q & 15]}));
                 v2f VA, VB;
+                v2f gq = {1.0f, 1.0f};
+                if constexpr (BAND) {  // bins ja and M - ja of this slot (thread 0's slots q >= 8: residue 256)
+                    const uint32_t ja = (uint32_t)r + (uint32_t)RES * (uint32_t)q - ((q >= 8 && is0) ? 3840u : 0u);
+                    gq = v2f{band_gain(p, ja), band_gain(p, (uint32_t)M - ja)};
+                }
                 if (q == 0)
-                    HOP4_PAIR<LOG2N, true>(va[q], vb[15 - q], wq, x0, key, VA, VB, is0);
+                    HOP4_PAIR<LOG2N, true, BAND>(va[q], vb[15 - q], wq, x0, key, VA, VB, is0, gq);
                 else
-                    HOP4_PAIR<LOG2N>(va[q], vb[15 - q], wq, (q < 8 ? x0 : x0h) + (uint32_t)q * dx, key, VA, VB);
+                    HOP4_PAIR<LOG2N, false, BAND>(va[q], vb[15 - q], wq, (q < 8 ? x0 : x0h) + (uint32_t)q * dx, key, VA, VB,
+                                                  false, gq);
                 va[q] = VA;
                 vb[15 - q] = VB;
             }
@@ -2297,7 +2309,9 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
         if (wv == 0) {
             // bin 4096 = M / 2 pairs with itself: exp(-2 pi i 4096 / N) = -i, counter of bin 4096
             v2f V8, V8b;
-            HOP4_PAIR<LOG2N>(s8, s8, v2f{0.0f, -1.0f}, 8u * (uint32_t)RES * key.mul + key.k0, key, V8, V8b);
+            const float g8 = BAND ? band_gain(p, 8u * (uint32_t)RES) : 1.0f;
+            HOP4_PAIR<LOG2N, false, BAND>(s8, s8, v2f{0.0f, -1.0f}, 8u * (uint32_t)RES * key.mul + key.k0, key, V8, V8b,
+                                          false, v2f{g8, g8});
             v2f na[8], nb0[8], nb1[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -2530,7 +2544,10 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
                 const bool hann = p.hann_rot != nullptr;
                 if (RC_V4 && hann && !(p.diag_flags & RC_DIAG_PREV_KERNEL)) {
                     const size_t lds4 = sizeof(float2) * (size_t)HOP4_LDS_FLOAT2;
-                    if (p.pitch == 1) hipLaunchKernelGGL((hop4_kernel<true>), grid, block, lds4, s, p);
+                    if (p.band_on) {
+                        if (p.pitch == 1) hipLaunchKernelGGL((hop4_kernel<true, true>), grid, block, lds4, s, p);
+                        else hipLaunchKernelGGL((hop4_kernel<false, true>), grid, block, lds4, s, p);
+                    } else if (p.pitch == 1) hipLaunchKernelGGL((hop4_kernel<true>), grid, block, lds4, s, p);
                     else hipLaunchKernelGGL((hop4_kernel<false>), grid, block, lds4, s, p);
                 } else if (RC_V3 && hann) {
                     const size_t lds3 = sizeof(float2) * (size_t)HOP3_LDS_FLOAT2;

@@ -364,6 +364,24 @@ def test_device_side_curated_kernels_match_host_kernels(N, f, p):
         assert_parity(got, oc.stretch_offline(x, N, f, 1.0, p, seed=17, kernel=_np_shift(sh)), f"shift {sh}")
 
 
+@pytest.mark.parametrize("p", [1, 2])
+def test_band_mask_fused_into_the_16384_kernel(monkeypatch, p):
+    """On the default 16384-sample window the band mask is applied inside hop4_kernel's pair stage (a per-bin gain
+    on the magnitudes) instead of the three-kernel pipeline: band edges at bin 0 and N/2 (thread 0's self-paired
+    bins), a negative gain (|g| is what survives the random phases), an empty band, several runs with seams, and
+    the unfused pipeline (ROCODER_DIAG=2) as a second opinion besides the oracle."""
+    ra = _engine_mod()
+    N, f = 16384, 8.0
+    x = np.stack([onp.synth_input(c, 40 * 1024 + 777) for c in range(2)])
+    for (lo, hi, gi, go) in ((0, 300, 0.5, 1.5), (4000, N // 2, -2.0, 0.25), (256, 256, 3.0, 0.0), (900, 100, 5.0, 0.75)):
+        got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=23, device_kernel=("band", lo, hi, gi, go))
+        ref = oc.stretch_offline(x, N, f, 1.0, p, seed=23, kernel=_np_band(lo, hi, gi, go))
+        assert_parity(got, ref, f"band {lo}..{hi} gains {gi}/{go} p={p}")
+    monkeypatch.setenv("ROCODER_DIAG", "2")
+    old = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=23, device_kernel=("band", 900, 100, 5.0, 0.75))
+    assert_parity(got, old, "fused vs unfused band mask")
+
+
 def test_device_kernel_and_host_kernel_are_exclusive():
     ra = _engine_mod()
     from rocoder_amd import _lib
