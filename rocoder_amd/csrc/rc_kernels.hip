@@ -2097,8 +2097,10 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
                 const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
                                __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
                 const v2f o = (head[q] + tail[q]) * er;
-                if (r == 0) dst[d] = o.x;                 // a0 = d * pitch
-                if (r + 1 == pitch) dst[d + 1] = o.y;     // a1 = a0 + 1 = (d + 1) * pitch
+                if (!(RC_ABLATE & 1024) || o.x == 1.2345e-30f) {  // (bit 1024, timing only: no output stores)
+                    if (r == 0) dst[d] = o.x;                 // a0 = d * pitch
+                    if (r + 1 == pitch) dst[d + 1] = o.y;     // a1 = a0 + 1 = (d + 1) * pitch
+                }
                 d += qs;
                 r += rs;
                 if (r >= pitch) {

@@ -8,7 +8,7 @@ dev = torch.device("cuda", 0)
 x = (torch.rand((2, 26_460_000), device=dev) - 0.5)
 stream = torch.cuda.Stream(dev)
 with torch.cuda.stream(stream):
-    e = rocoder_amd.Engine(window_len=16384, factor=8.0, pitch_multiple=3, channels=2, seed=1)
+    e = rocoder_amd.Engine(window_len=16384, factor=float(sys.argv[1]) if len(sys.argv) > 1 else 8.0, pitch_multiple=int(sys.argv[2]) if len(sys.argv) > 2 else 3, channels=2, seed=1)
     out = torch.empty((2, e.output_len(x.shape[1])), device=dev)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 1.5:
