@@ -76,7 +76,10 @@ typedef struct rc_config {
      *   RC_DK_GAIN   Y[j] = dk_gain X[j]                      (README.md:121-128 with any factor)
      *   RC_DK_BAND   Y[j] = (dk_lo_bin <= min(j, N - j) <= dk_hi_bin ? dk_gain : dk_gain_outside) X[j]
      *   RC_DK_SHIFT  Y[j] = X[j - dk_shift_bins] for 0 <= j <= N/2 (0 where j - shift leaves [0, N/2]),
-     *                Y[N - j] = conj(Y[j]) : the spectrum of a real signal moved up or down by whole bins */
+     *                Y[N - j] = conj(Y[j]) : the spectrum of a real signal moved up or down by whole bins
+     * Cost: GAIN rides on the amplitude of the fused kernels (free); BAND is applied inside the fused kernel of the
+     * default 16384-sample window (a few instructions per bin pair) and otherwise, like SHIFT, runs as forward
+     * transform -> kernel -> resynthesis on device scratch. */
     uint32_t device_kernel;
     float dk_gain, dk_gain_outside;
     uint32_t dk_lo_bin, dk_hi_bin;
