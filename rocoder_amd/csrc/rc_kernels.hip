@@ -2925,6 +2925,9 @@ __device__ __forceinline__ void tail_st(GV2W p, v2f v) {
     if (RC_B4_TAILNT) __builtin_nontemporal_store(v, p);
     else *p = v;
 }
+#ifndef RC_B4_DMA
+#define RC_B4_DMA 0
+#endif
 #ifndef RC_B4_ABL
 #define RC_B4_ABL 0  // timing-only ablations of big4_kernel: 1 no input loads, 2 no tail scratch traffic, 4 no output stores
 #endif
@@ -2993,6 +2996,11 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
     const bool is0 = tid == 0;
     Stamps stp;
     stp.init();
+    // RC_B4_DMA (R = 32): the next hop's whole window (N floats = the exchange buffer's size) is fetched by LDS-DMA
+    // (global_load_lds_dwordx4: no VGPRs) into the exchange buffer while it is idle - from the last E4 read to the
+    // next E1 write - so that its latency runs under I3 and the epilogue instead of in front of F1
+    constexpr bool DMA = RC_B4_DMA && R == 32;
+    bool dma_ready = false;
     for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         int tt = tid;  // per-hop opaque copy for the scratch addresses (hoisted, they would be 2 PH live VGPRs)
@@ -3012,11 +3020,22 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             // every load of the hop in flight at once when the window is computed (one memory latency per
             // hop); batches of 16 when the window comes from its table too (register budget)
             constexpr int LB = HANN ? (R > 32 ? RC_B4_LB : R) : 16;
+            if (DMA && dma_ready) {  // every wave waits for its own DMAs, then all of them are visible to all.
+                // The PH output stores of the previous hop were issued behind the DMAs and may stay in flight
+                // (vector memory operations retire in order)
+                if (PITCH1 && k - 1 >= k_begin) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
 #pragma unroll
             for (int q0 = 0; q0 < R; q0 += LB) {
                 float xr0[LB], xr1[LB], wr0[HANN ? 1 : LB], wr1[HANN ? 1 : LB];
 #pragma unroll
                 for (int q = 0; q < LB; ++q) {
+                    if (DMA && dma_ready) {  // (uniform) z[n], n = tid + 512 q, sits at float2 slot n
+                        const float2 zz = lds[tid + T * (q0 + q)];
+                        xr0[q] = zz.x;
+                        xr1[q] = zz.y;
+                    } else
                     if (RC_B4_ABL & 1) {  // timing only: no input loads
                         xr0[q] = (float)(lane2 + q0 + q) + (float)k;
                         xr1[q] = xr0[q] * 0.5f;
@@ -3235,6 +3254,22 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 BIG4_BAR();
 #pragma unroll
                 for (int q = 0; q < 32; ++q) y[q + 32 * g] = to_v(lds[tid + (q << 9)]);
+            }
+        }
+        if constexpr (DMA) {
+            dma_ready = k + 1 < k_end;
+            if (dma_ready) {
+                BIG4_BAR();  // every wave has its E4 data: the buffer is free
+                typedef __attribute__((address_space(3))) void *LP;
+                typedef const __attribute__((address_space(1))) void *GP;
+                GF s2 = hop_src(p, xc, xt, k + 1);
+                float *ldsf = reinterpret_cast<float *>(lds);
+                const int lane = tid & 63;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {  // 16 KiB per wave: 16 pieces of 64 lanes x 16 bytes
+                    const int c = wv * 16 + j;
+                    __builtin_amdgcn_global_load_lds((GP)(s2 + c * 256 + lane * 4), (LP)(ldsf + c * 256), 16, 0, 0);
+                }
             }
         }
         stp.mark(8);
