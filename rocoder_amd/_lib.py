@@ -5,11 +5,15 @@ Python/CPU fallback: if the library is missing, loading fails loudly.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ROCODER_HIP_LIB") or os.path.join(_HERE, "librocoder_hip.so")
+# the same sources built with -DRC_TEST_HOOKS=1 (`make hooks`): reads ROCODER_DIAG and the run-planner tuning
+# variables at rc_engine_create and contains the previous kernel generation. Tests and A/B tools only.
+HOOKS_PATH = os.path.join(_HERE, "librocoder_hip_hooks.so")
 
 RC_OK, RC_WOULD_BLOCK = 0, 1
 RC_EINVAL, RC_ENODEVICE, RC_EUNSUPPORTED, RC_ENOMEM, RC_EHIP, RC_ECAPACITY = -1, -2, -3, -4, -5, -6
@@ -107,14 +111,10 @@ class RocoderError(RuntimeError):
         self.code = code
 
 
-def lib() -> C.CDLL:
-    """Load the engine library (fails loudly when it has not been built)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _load(path: str) -> C.CDLL:
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
     # PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7). Two
     # HIP runtimes in one process do not work ("No HIP GPUs are available" for the second), so if
@@ -124,16 +124,40 @@ def lib() -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = L
     return L
 
 
-def check(rc: int) -> int:
+def lib() -> C.CDLL:
+    """Load the engine library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        _lib = _load(LIB_PATH)
+    return _lib
+
+
+_hooks = None
+
+
+@contextlib.contextmanager
+def hooks_library():
+    """Tests / A-B tools: inside the block `lib()` is the test-hook build (it alone honours ROCODER_DIAG,
+    ROCODER_ROUNDS, ROCODER_MIN_RUN, ROCODER_B4_ROUNDS). Engines created inside keep it for their lifetime."""
+    global _lib, _hooks
+    if _hooks is None:
+        _hooks = _load(HOOKS_PATH)
+    prev, _lib = _lib, _hooks
+    try:
+        yield _hooks
+    finally:
+        _lib = prev
+
+
+def check(rc: int, L: C.CDLL | None = None) -> int:
     if rc < 0:
-        raise RocoderError(rc, lib().rc_last_error().decode(errors="replace"))
+        raise RocoderError(rc, (L or lib()).rc_last_error().decode(errors="replace"))
     return rc

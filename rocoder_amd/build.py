@@ -1,4 +1,4 @@
-"""In-tree build of the gfx950 engine library (hipcc cross-compiles without a GPU)."""
+"""In-tree build of the gfx950 engine library and of its test-hook twin (hipcc cross-compiles without a GPU)."""
 from __future__ import annotations
 
 import os
@@ -9,7 +9,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+    cmd = ["make", "-j6", "-C", CSRC, "all", "hooks"] + (["-B"] if force else [])
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)

@@ -1,0 +1,614 @@
+#include "rc_dit.hpp"
+
+namespace rc {
+namespace {
+
+// ======================= fused large-window kernel (N = 32768 / 65536) ==========================
+// big_a / big_b / big_cr above move ~8 N bytes of scratch per hop through HBM. big4_kernel keeps a whole
+// hop inside one workgroup: T = 512 threads hold the M = N/2 = 512 R complex points, R = 32 (N = 32768) or
+// 64 (N = 65536) per thread, b = log2 R (tests/dev/proto_big.py is the index model):
+//   F1  stages 0..b-1     on the R registers (constants only), thread t = low 9 bits of the sample index
+//   F2  stages b..b+4     on R/32 groups of 32 registers, thread = (lf = p0..p4, uu = the top 4 position bits)
+//   F3  stages b+5..b+8   on R/16 sets of 16 registers: thread tau holds the residues tau and RES - tau
+//                         (and tau + 512, RES - 512 - tau for R = 64), RES = 2^(b+5), so every (j, M - j) bin
+//                         pair sits in one thread and the middle stage runs in registers as in hop4_kernel
+//   I1 / I2 / I3 mirror them (4, 5 and b stages); the synthesis window and the two-term overlap-add follow
+//   in registers (R = 32) - for R = 64 the carried tail y_{k-1}[H..] does not fit the register file next to
+//   128 data registers and travels through a per-workgroup scratch of 128 KiB (written and re-read by the
+//   same CU one hop later: L2 / Infinity-Cache traffic, not HBM).
+// Exchanges go through one 16 400-element LDS buffer (131 KB: one workgroup = 8 waves per CU), a single
+// round for R = 32, two rounds of 32 registers per thread for R = 64.
+struct W64Tab {
+    float re[32], im[32];
+};
+constexpr W64Tab make_w64() {  // exp(-2 pi i c / 64), c < 32
+    W64Tab t{};
+    for (int c = 0; c < 32; ++c) {
+        t.re[c] = (float)cx_cos(2.0 * CX_PI * c / 64.0);
+        t.im[c] = (float)(-cx_sin(2.0 * CX_PI * c / 64.0));
+    }
+    return t;
+}
+__device__ constexpr W64Tab W64 = make_w64();
+// default-window fast path of big4_kernel (as HANN_W14 for hop4): value(i) = base + c[q] cos(beta) + s[q] sin(beta)
+// for sample i = 1024 q + 2 t + e, beta = 2 pi (2 t + e) / (len - 1)
+struct HannK64 {
+    float c[64], s[64];
+};
+constexpr HannK64 make_hann_k64(double amp, int len, int count) {
+    HannK64 k{};
+    for (int q = 0; q < 64; ++q) {
+        const double a = q < count ? 2.0 * CX_PI * 1024.0 * q / (double)(len - 1) : 0.0;
+        k.c[q] = (float)(-amp * cx_cos(a));
+        k.s[q] = (float)(amp * cx_sin(a));
+    }
+    return k;
+}
+__device__ constexpr HannK64 HANN_W15 = make_hann_k64(0.5, 32768, 32);
+__device__ constexpr HannK64 HANN_E15 = make_hann_k64(HANN_ENV_AMP, 16384, 16);
+__device__ constexpr HannK64 HANN_W16 = make_hann_k64(0.5, 65536, 64);
+__device__ constexpr HannK64 HANN_E16 = make_hann_k64(HANN_ENV_AMP, 32768, 32);
+
+// dit_stages for up to 64 registers: 64th-root constants, otherwise the same arithmetic
+template <int NREG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L>
+__device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f}) {
+    const v2f sgn = CONJ ? v2f{1.0f, -1.0f} : v2f{-1.0f, 1.0f};
+    v2f bases[S_HI - S_LO + 1];
+    if (HAS_L) {
+        bases[S_HI - S_LO] = wfine;
+#pragma unroll
+        for (int s = S_HI - 1; s >= S_LO; --s) bases[s - S_LO] = vcmul(bases[s + 1 - S_LO], bases[s + 1 - S_LO]);
+    }
+#pragma unroll
+    for (int s = S_LO; s <= S_HI; ++s) {
+        const int rb = s - REG_LO;
+        const int half = 1 << rb;
+        if (!HAS_L) {
+#pragma unroll
+            for (int q0 = 0; q0 < NREG; ++q0) {
+                if (q0 & half) continue;
+                const int q1 = q0 | half;
+                const int c = q0 & (half - 1);
+                const int kidx = c * (32 >> rb);  // exp(-2 pi i c / 2^(rb+1)) = W64^kidx
+                const v2f a = v[q0], b = v[q1];
+                const v2f kc = {W64.re[kidx & 31], W64.im[kidx & 31]};
+                if (c == 0) {
+                    v[q0] = a + b;
+                    v[q1] = a - b;
+                } else if (kidx == 16) {
+                    const v2f ib = __builtin_shufflevector(b, b, 1, 0) * sgn;
+                    v[q0] = a - ib;
+                    v[q1] = a + ib;
+                } else {
+                    const v2f w2 = v2f{kc.y, kc.y} * sgn;
+                    vdit(a, b, kc, w2, v[q0], v[q1]);
+                }
+            }
+        } else {
+            const v2f base = bases[s - S_LO];
+            constexpr int NCMAX = NREG / 4 > 0 ? NREG / 4 : 1;
+            const int nc = half > 1 ? half / 2 : 1;
+            v2f tw[NCMAX];
+#pragma unroll
+            for (int c = 0; c < NCMAX; ++c) {
+                if (c >= nc) continue;
+                const int kidx = c * (32 >> rb);
+                const v2f kc = {W64.re[kidx & 31], W64.im[kidx & 31]};
+                tw[c] = c == 0 ? base : vcmul(base, kc);
+            }
+#pragma unroll
+            for (int q0 = 0; q0 < NREG; ++q0) {
+                if (q0 & half) continue;
+                const int q1 = q0 | half;
+                const int c = q0 & (half - 1);
+                const v2f a = v[q0], b = v[q1];
+                if (c < nc) vdit_m<CONJ>(a, b, tw[c], v[q0], v[q1]);
+                else vdit_rot_m<CONJ>(a, b, tw[c - nc], v[q0], v[q1]);
+            }
+        }
+    }
+}
+
+#ifndef RC_B4_LB
+#define RC_B4_LB 32
+#endif
+#ifndef RC_B4_TAILREG_MAX
+#define RC_B4_TAILREG_MAX 32  // largest R whose carried tail lives in registers (above: per-workgroup scratch)
+#endif
+#ifndef RC_B4_LGKM
+#define RC_B4_LGKM 1
+#endif
+// the exchange barriers order LDS traffic only: global stores of the epilogue (this thread's own output and tail
+// addresses) may still be in flight when the next hop starts
+#define BIG4_BAR()                                                                       \
+    do {                                                                                 \
+        if (RC_B4_LGKM) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
+        else __syncthreads();                                                            \
+    } while (0)
+#ifndef RC_B4_TAILNT
+#define RC_B4_TAILNT 0  // 1: non-temporal tail-scratch accesses (experiment)
+#endif
+__device__ __forceinline__ v2f tail_ld(GV2 p) { return RC_B4_TAILNT ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void tail_st(GV2W p, v2f v) {
+    if (RC_B4_TAILNT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+#ifndef RC_B4_DMA
+#define RC_B4_DMA 0
+#endif
+#ifndef RC_B4_ABL
+#define RC_B4_ABL 0  // timing-only ablations of big4_kernel: 1 no input loads, 2 no tail scratch traffic, 4 no output stores
+#endif
+#ifndef RC_B4_EB
+#define RC_B4_EB 4
+#endif
+#ifndef RC_B4_TPRE
+#define RC_B4_TPRE 0
+#endif
+constexpr int BIG4_T = 512;
+constexpr int BIG4_XBUF = 16400;  // exchange buffer, float2 slots (16384 + the 15 of the E1 / E3 index map)
+// tables behind the buffer: W_M^r [TA], W_N^r [TR] for r <= RES/2, thread 0's second twiddle base
+constexpr int big4_lds_float2(int R) { return BIG4_XBUF + 2 * (16 * R + 1) + 8; }
+
+template <int R, bool PITCH1, bool HANN>
+__global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
+    constexpr int b = clog2(R), m = b + 9, LOG2N = m + 1, M = 1 << m, H = M, T = BIG4_T;
+    constexpr int RES = 1 << (b + 5), G = R / 32, NS = R / 16, PH = R / 2;
+    constexpr int T_A = BIG4_XBUF, T_R = T_A + RES / 2 + 1, SCR = T_R + RES / 2 + 1;
+    constexpr bool TAIL_GLOBAL = R > RC_B4_TAILREG_MAX;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int tid = threadIdx.x;
+    const uint32_t run = blockIdx.x % p.runs_per_channel;
+    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
+    int64_t k_end = k_begin + p.run_len;
+    if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
+    if (k_begin >= k_end) return;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
+    GV2W tsc = (GV2W)p.ybuf + (size_t)blockIdx.x * (H / 2);  // TAIL_GLOBAL: this workgroup's tail scratch
+    if constexpr (TAIL_GLOBAL) {  // uniform base in SGPRs + a 32-bit lane offset: no 64-bit address per access
+        const unsigned long long ta = (unsigned long long)tsc;
+        const unsigned tlo = __builtin_amdgcn_readfirstlane((unsigned)ta);
+        const unsigned thi = __builtin_amdgcn_readfirstlane((unsigned)(ta >> 32));
+        tsc = (GV2W)(((unsigned long long)thi << 32) | tlo);
+    }
+    const unsigned lane2 = 2u * (unsigned)tid;
+    const uint32_t pitch = PITCH1 ? 1u : p.pitch;
+    const int wv = tid >> 6;
+    {
+        GV2 wt = (GV2)p.wtab;  // [RES/2 + 1] exp(-2 pi i k / M)
+        GV2 rt = (GV2)p.rtab;  // exp(-2 pi i j / N)
+        for (int i = tid; i <= RES / 2; i += T) {
+            lds[T_A + i] = ldg2(wt + i);
+            lds[T_R + i] = ldg2(rt + i);
+        }
+        if (tid == 0) {  // W_N^(RES/2 - M/2) = i W_N^(RES/2): thread 0's twiddle base for its second residue
+            const float2 wq = ldg2(rt + RES / 2);
+            lds[SCR] = make_float2(-wq.y, wq.x);
+        }
+        __syncthreads();
+    }
+    v2f tail[TAIL_GLOBAL ? 1 : PH];
+    if constexpr (!TAIL_GLOBAL) {
+#pragma unroll
+        for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
+    } else {
+#pragma unroll
+        for (int q = 0; q < PH; ++q) stg2(tsc + T * q + (unsigned)tid, make_float2(0.f, 0.f));
+    }
+    // thread identities
+    const int lf = tid & 31, uu = tid >> 5;   // F2
+    const int l4 = tid & 15, hi = tid >> 4;   // I2
+    const bool is0 = tid == 0;
+    Stamps stp;
+    stp.init();
+    // RC_B4_DMA (R = 32): the next hop's whole window (N floats = the exchange buffer's size) is fetched by LDS-DMA
+    // (global_load_lds_dwordx4: no VGPRs) into the exchange buffer while it is idle - from the last E4 read to the
+    // next E1 write - so that its latency runs under I3 and the epilogue instead of in front of F1
+    constexpr bool DMA = RC_B4_DMA && R == 32;
+    bool dma_ready = false;
+    for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
+        const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+        int tt = tid;  // per-hop opaque copy for the scratch addresses (hoisted, they would be 2 PH live VGPRs)
+        opaque(tt);
+        v2f v[R];
+        {   // register brev_b(q) := z[q * T + t] * window
+            GF src = hop_src(p, xc, xt, k);
+            GF win = per_hop(p.window);
+            v2f cbW = {0.f, 0.f}, sbW = cbW;
+            if constexpr (HANN) {  // {cos, sin}(beta) of this thread's two samples, from the engine's table
+                GV2 hr = (GV2)per_hop(p.hann_rot) + 2 * tid;
+                const float2 a0 = ldg2(hr), a1 = ldg2(hr + 1);
+                cbW = v2f{a0.x, a1.x};
+                sbW = v2f{a0.y, a1.y};
+            }
+            const HannK64 &HW = R == 32 ? HANN_W15 : HANN_W16;
+            // every load of the hop in flight at once when the window is computed (one memory latency per
+            // hop); batches of 16 when the window comes from its table too (register budget)
+            constexpr int LB = HANN ? (R > 32 ? RC_B4_LB : R) : 16;
+            if (DMA && dma_ready) {  // every wave waits for its own DMAs, then all of them are visible to all.
+                // The PH output stores of the previous hop were issued behind the DMAs and may stay in flight
+                // (vector memory operations retire in order)
+                if (PITCH1 && k - 1 >= k_begin) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+#pragma unroll
+            for (int q0 = 0; q0 < R; q0 += LB) {
+                float xr0[LB], xr1[LB], wr0[HANN ? 1 : LB], wr1[HANN ? 1 : LB];
+#pragma unroll
+                for (int q = 0; q < LB; ++q) {
+                    if (DMA && dma_ready) {  // (uniform) z[n], n = tid + 512 q, sits at float2 slot n
+                        const float2 zz = lds[tid + T * (q0 + q)];
+                        xr0[q] = zz.x;
+                        xr1[q] = zz.y;
+                    } else
+                    if (RC_B4_ABL & 1) {  // timing only: no input loads
+                        xr0[q] = (float)(lane2 + q0 + q) + (float)k;
+                        xr1[q] = xr0[q] * 0.5f;
+                    } else {
+                        xr0[q] = (src + 2 * T * (q0 + q))[lane2];
+                        xr1[q] = (src + 2 * T * (q0 + q))[lane2 + 1];
+                    }
+                    if constexpr (!HANN) {
+                        wr0[q] = (win + 2 * T * (q0 + q))[lane2];
+                        wr1[q] = (win + 2 * T * (q0 + q))[lane2 + 1];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < LB; ++q) {
+                    v2f wq;
+                    if constexpr (HANN)
+                        wq = __builtin_elementwise_fma(v2f{HW.s[q0 + q], HW.s[q0 + q]}, sbW,
+                             __builtin_elementwise_fma(v2f{HW.c[q0 + q], HW.c[q0 + q]}, cbW, v2f{0.5f, 0.5f}));
+                    else
+                        wq = v2f{wr0[q], wr1[q]};
+                    v[brev_c(q0 + q, b)] = v2f{xr0[q], xr1[q]} * wq;
+                }
+            }
+            stp.mark(0);
+            dit_g<R, 0, b - 1, 0, false, false>(v);
+        }
+        stp.mark(1);
+        // ---- E1: F1 -> F2, round g moves the registers with position bit 5 = g
+        v2f w[R];
+        {
+            const int bs = (int)(__brev((unsigned)tid) >> 23);           // brev9(t)
+            const int b1s = (bs << 5) + (bs >> 5);                       // e1(q | brev9(t) << 5) = q + this
+            const int b1l = lf + (uu << 10) + uu;                        // e1(lf | j << 5 | uu << 10) = (j << 5) + this
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                BIG4_BAR();
+#pragma unroll
+                for (int q = 0; q < 32; ++q) lds[b1s + q] = to_f2(v[32 * g + q]);
+                BIG4_BAR();
+#pragma unroll
+                for (int j = 0; j < 32; ++j) w[32 * g + j] = to_v(lds[b1l + (j << 5)]);
+            }
+        }
+        stp.mark(2);
+        {   // F2: stages b..b+4 on each group; base W_RES^(lf | g << 5) = W_M^(16 lf) * (g ? W_64 : 1)
+            const v2f wf0 = to_v(lds[T_A + 16 * lf]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                v2f grp[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) grp[j] = w[32 * g + j];
+                dit_g<32, b, b + 4, b, false, true>(grp, g ? vcmul(wf0, v2f{W64.re[1], W64.im[1]}) : wf0);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) w[32 * g + j] = grp[j];
+            }
+        }
+        stp.mark(3);
+        // ---- E2: F2 -> F3. slot = (residue mod 1024) | uu << 10; R = 64: round 0 = residues < 1024
+        v2f st[NS][16];
+        {
+            const int b2s = lf | (uu << 10);
+#pragma unroll
+            for (int rnd = 0; rnd < G; ++rnd) {
+                BIG4_BAR();
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) {
+                    if (R == 32) lds[b2s + (kk << 5)] = to_f2(w[kk]);
+                    else lds[b2s + ((kk >> 4) << 5) + ((kk & 15) << 6)] = to_f2(w[32 * (kk >> 4) + 16 * rnd + (kk & 15)]);
+                }
+                BIG4_BAR();
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (R == 64 && ((s & 1) != rnd)) continue;
+                    const int r0 = tid + 512 * (s >> 1);
+                    const int res = (s & 1) ? ((r0 == 0 ? RES / 2 : RES - r0) & 1023) : (r0 & 1023);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) st[s][q] = to_v(lds[res + (q << 10)]);
+                }
+            }
+        }
+        stp.mark(4);
+        // ---- F3 on every set, middle stage on every (A, B) pair of sets, I1
+#pragma unroll
+        for (int gp = 0; gp < NS / 2; ++gp) {
+            const int r = tid + 512 * gp;
+            v2f(&va)[16] = st[2 * gp];
+            v2f(&vb)[16] = st[2 * gp + 1];
+            {
+                const v2f wa = to_v(lds[T_A + r]);  // W_M^r
+                const v2f k16 = {W32_RE[2], W32_IM[2]};
+                v2f wb = vcmul(v2f{wa.x, -wa.y}, k16);  // W_M^(RES - r) = W_16 conj(W_M^r)
+                if (gp == 0 && is0) wb = v2f{W32_RE[1], W32_IM[1]};  // thread 0: residue RES/2 -> W_32
+                dit_g<16, b + 5, b + 8, b + 5, false, true>(va, wa);
+                dit_g<16, b + 5, b + 8, b + 5, false, true>(vb, wb);
+            }
+            // thread 0, group 0: residues 0 and RES/2 pair with themselves (hop4_kernel's re-deal)
+            const bool sp = gp == 0 && is0;
+            v2f s8 = va[8];
+            if (gp == 0 && wv == 0) {
+                const v2f va0 = va[0];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const v2f a = va[8 + i], b0 = vb[i], b1 = vb[8 + i];
+                    const v2f nx = i < 7 ? va[9 + i] : va0;
+                    va[8 + i] = vsel(sp, b0, a);
+                    vb[i] = vsel(sp, b1, b0);
+                    vb[8 + i] = vsel(sp, nx, b1);
+                }
+            }
+            {
+                const float2 wrl = lds[T_R + r];
+                const float2 wrh = lds[sp ? SCR : T_R + r];
+                const uint32_t x0 = (uint32_t)r * key.mul + key.k0;
+                const uint32_t dx = (uint32_t)RES * key.mul;
+                const uint32_t x0h = x0 - (sp ? (uint32_t)(M / 2 - RES / 2) * key.mul : 0u);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float2 wr = q < 8 ? wrl : wrh;
+                    const v2f wrv = to_v(wr);
+                    const v2f wq = q == 0 ? wrv : (q == 8 ? v2f{wr.y, -wr.x}
+                                   : vcmul(wrv, v2f{W32_RE[q & 15], W32_IM[q & 15]}));
+                    v2f VA, VB;
+                    if (q == 0 && gp == 0)
+                        pair_regs_pk4<LOG2N, true>(va[q], vb[15 - q], wq, x0, key, VA, VB, sp);
+                    else
+                        pair_regs_pk4<LOG2N>(va[q], vb[15 - q], wq, (q < 8 ? x0 : x0h) + (uint32_t)q * dx, key, VA, VB);
+                    va[q] = VA;
+                    vb[15 - q] = VB;
+                }
+            }
+            if (gp == 0 && wv == 0) {  // bin M/2 pairs with itself; un-deal thread 0's registers
+                v2f V8, V8b;
+                pair_regs_pk4<LOG2N>(s8, s8, v2f{0.0f, -1.0f}, 8u * (uint32_t)RES * key.mul + key.k0, key, V8, V8b);
+                v2f na[8], nb0[8], nb1[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    na[i] = vsel(sp, i == 0 ? V8 : vb[7 + i], va[8 + i]);
+                    nb0[i] = vsel(sp, va[8 + i], vb[i]);
+                    nb1[i] = vsel(sp, vb[i], vb[8 + i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    va[8 + i] = na[i];
+                    vb[i] = nb0[i];
+                    vb[8 + i] = nb1[i];
+                }
+            }
+            // I1: inverse stages 0..3, register index = brev4(q)
+            v2f pa[16], pb[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                pa[brev_c(q, 4)] = va[q];
+                pb[brev_c(q, 4)] = vb[q];
+            }
+            dit_g<16, 0, 3, 0, true, false>(pa);
+            dit_g<16, 0, 3, 0, true, false>(pb);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                va[q] = pa[q];
+                vb[q] = pb[q];
+            }
+        }
+        stp.mark(5);
+        // ---- E3: I1 -> I2. element P = q' | brev_{b+5}(residue) << 4; R = 64: P4 (= residue >= 1024) is the round
+        {
+#pragma unroll
+            for (int rnd = 0; rnd < G; ++rnd) {
+                BIG4_BAR();
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (R == 64 && ((s & 1) != rnd)) continue;
+                    const int r0 = tid + 512 * (s >> 1);
+                    const int res = (s & 1) ? (r0 == 0 ? RES / 2 : RES - r0) : r0;
+                    const int br = (int)(__brev((unsigned)res) >> (32 - (b + 5)));  // brev_{b+5}(residue) = P4..
+                    const int hiP = R == 32 ? br : (br >> 1);                     // drop P4 for R = 64
+                    const int n0 = hiP << 4;                                     // reduced index, q' = 0
+                    const int base = n0 + ((n0 >> 10) & 15);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) lds[base + q] = to_f2(st[s][q]);
+                }
+                BIG4_BAR();
+#pragma unroll
+                for (int kk = 0; kk < 32; ++kk) {
+                    // R = 32: register kk = P4..P8; R = 64: kk = (group g = P14) << 4 | (P5..P8), P4 = rnd
+                    const int n = R == 32 ? (l4 | (kk << 4) | (hi << 9))
+                                          : (l4 | ((kk & 15) << 4) | (hi << 8) | ((kk >> 4) << 13));
+                    const v2f x = to_v(lds[n + ((n >> 10) & 15)]);
+                    if (R == 32) v[kk] = x;
+                    else v[32 * (kk >> 4) + 2 * (kk & 15) + rnd] = x;
+                }
+            }
+        }
+        stp.mark(6);
+        {   // I2: inverse stages 4..8 on each group, base W_512^l4 = W_M^(l4 R)
+            const v2f wf = to_v(lds[T_A + l4 * R]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                v2f grp[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) grp[j] = v[32 * g + j];
+                dit_g<32, 4, 8, 4, true, true>(grp, wf);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) v[32 * g + j] = grp[j];
+            }
+        }
+        stp.mark(7);
+        // ---- E4: I2 -> I3 (registers = P9.., thread = P0..P8), round g = P14
+        v2f y[R];
+        {
+            const int b4s = l4 | (hi << 9);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                BIG4_BAR();
+#pragma unroll
+                for (int j = 0; j < 32; ++j) lds[b4s + (j << 4)] = to_f2(v[32 * g + j]);
+                BIG4_BAR();
+#pragma unroll
+                for (int q = 0; q < 32; ++q) y[q + 32 * g] = to_v(lds[tid + (q << 9)]);
+            }
+        }
+        if constexpr (DMA) {
+            dma_ready = k + 1 < k_end;
+            if (dma_ready) {
+                BIG4_BAR();  // every wave has its E4 data: the buffer is free
+                typedef __attribute__((address_space(3))) void *LP;
+                typedef const __attribute__((address_space(1))) void *GP;
+                GF s2 = hop_src(p, xc, xt, k + 1);
+                float *ldsf = reinterpret_cast<float *>(lds);
+                const int lane = tid & 63;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {  // 16 KiB per wave: 16 pieces of 64 lanes x 16 bytes
+                    const int c = wv * 16 + j;
+                    __builtin_amdgcn_global_load_lds((GP)(s2 + c * 256 + lane * 4), (LP)(ldsf + c * 256), 16, 0, 0);
+                }
+            }
+        }
+        stp.mark(8);
+        // R = 64: the carried tail comes back from the scratch; requested here, behind the last exchange, so that
+        // its latency hides under I3 (v is dead: there are registers for it)
+        constexpr bool TPRE = TAIL_GLOBAL && RC_B4_TPRE;
+        v2f tpre[TPRE ? PH : 1];
+        if constexpr (TPRE) {
+#pragma unroll
+            for (int q = 0; q < PH; ++q) tpre[q] = tail_ld((GV2)tsc + T * q + (unsigned)tt);
+        }
+        dit_g<R, 9, m - 1, 9, true, true>(y, to_v(lds[T_A + tid]));
+        stp.mark(9);
+        // ---- epilogue: synthesis window, overlap-add, store (tail in registers or in the scratch)
+        {
+            GF win = per_hop(p.window);
+            GF esrc = per_hop(p.env);
+            v2f cbW = {0.f, 0.f}, sbW = cbW, cbE = cbW, sbE = cbW;
+            if constexpr (HANN) {
+                GV2 hr = (GV2)per_hop(p.hann_rot) + 2 * tid;
+                const float2 a0 = ldg2(hr), a1 = ldg2(hr + 1), e0r = ldg2(hr + 2 * T), e1r = ldg2(hr + 2 * T + 1);
+                cbW = v2f{a0.x, a1.x};
+                sbW = v2f{a0.y, a1.y};
+                cbE = v2f{e0r.x, e1r.x};
+                sbE = v2f{e0r.y, e1r.y};
+            }
+            const HannK64 &HW = R == 32 ? HANN_W15 : HANN_W16;
+            const HannK64 &HE = R == 32 ? HANN_E15 : HANN_E16;
+            const v2f hf = {0.5f, 0.5f};
+            // pair_regs_pk4 leaves the -1/(4N) of the magnitudes out (a power of two): it rides on the amplitude
+            const float ak = p.amp * (-0.25f / (float)(1 << LOG2N));
+            const v2f ampk = {ak, ak};
+            const int64_t g0 = k * (int64_t)H;
+            GFW dst = outc + (g0 / (int64_t)pitch - p.out_origin);
+            const uint32_t kr = (uint32_t)(g0 % pitch);
+            constexpr int EB = R > 32 ? RC_B4_EB : 8;  // batch of table / tail loads in flight (register budget)
+            constexpr bool TPIPE = TAIL_GLOBAL && !TPRE;  // tail loads one batch ahead of their use
+            v2f tnx[TPIPE ? EB : 1];
+            if constexpr (TPIPE) {
+#pragma unroll
+                for (int q = 0; q < EB; ++q)
+                    tnx[q] = (RC_B4_ABL & 2) ? v2f{0.f, 0.f} : tail_ld((GV2)tsc + T * q + (unsigned)tt);
+            }
+#pragma unroll
+            for (int q0 = 0; q0 < PH; q0 += EB) {
+                float wr0[EB], wr1[EB], wt0[EB], wt1[EB], e0[EB], e1[EB];
+                v2f tq[EB];
+                if constexpr (TPIPE) {
+#pragma unroll
+                    for (int q = 0; q < EB; ++q) tq[q] = tnx[q];
+                    if (q0 + EB < PH) {
+#pragma unroll
+                        for (int q = 0; q < EB; ++q)
+                            tnx[q] = (RC_B4_ABL & 2) ? v2f{0.f, 0.f} : tail_ld((GV2)tsc + T * (q0 + EB + q) + (unsigned)tt);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < EB; ++q) {
+                    if constexpr (!HANN) {
+                        wr0[q] = (win + 2 * T * (q0 + q))[lane2];
+                        wr1[q] = (win + 2 * T * (q0 + q))[lane2 + 1];
+                        wt0[q] = (win + 2 * T * (q0 + q + PH))[lane2];
+                        wt1[q] = (win + 2 * T * (q0 + q + PH))[lane2 + 1];
+                        e0[q] = (esrc + 2 * T * (q0 + q))[lane2];
+                        e1[q] = (esrc + 2 * T * (q0 + q))[lane2 + 1];
+                    } else {
+                        const v2f wh = __builtin_elementwise_fma(v2f{HW.s[q0 + q], HW.s[q0 + q]}, sbW,
+                                       __builtin_elementwise_fma(v2f{HW.c[q0 + q], HW.c[q0 + q]}, cbW, hf));
+                        const v2f wt = __builtin_elementwise_fma(v2f{HW.s[q0 + q + PH], HW.s[q0 + q + PH]}, sbW,
+                                       __builtin_elementwise_fma(v2f{HW.c[q0 + q + PH], HW.c[q0 + q + PH]}, cbW, hf));
+                        const v2f ev = __builtin_elementwise_fma(v2f{HE.s[q0 + q], HE.s[q0 + q]}, sbE,
+                                       __builtin_elementwise_fma(v2f{HE.c[q0 + q], HE.c[q0 + q]}, cbE, hf));
+                        wr0[q] = wh.x, wr1[q] = wh.y, wt0[q] = wt.x, wt1[q] = wt.y, e0[q] = ev.x, e1[q] = ev.y;
+                    }
+                    if constexpr (TPRE) tq[q] = tpre[q0 + q];
+                    else if constexpr (TAIL_GLOBAL) {}
+                    else tq[q] = tail[q0 + q];
+                }
+#pragma unroll
+                for (int q = 0; q < EB; ++q) {
+                    const v2f head = y[q0 + q] * v2f{wr0[q], wr1[q]};
+                    const v2f nt = y[q0 + q + PH] * v2f{wt0[q], wt1[q]};
+                    if (k >= k_begin) {
+                        // stretcher.rs:97-100 operation order
+                        const v2f o = (head + tq[q]) * v2f{e0[q], e1[q]} * ampk;
+                        if constexpr (PITCH1) {
+                            if (!(RC_B4_ABL & 4) || o.x == 1.2345f)  // (bit 4, timing only: no output stores)
+                            __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * (q0 + q) + lane2));
+                        } else {
+                            const uint32_t a0 = kr + 2u * (uint32_t)(tid + T * (q0 + q)), a1 = a0 + 1;
+                            const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
+                            if (d0 * pitch == a0) dst[d0] = o.x;
+                            if (d1 * pitch == a1) dst[d1] = o.y;
+                        }
+                    }
+                    if constexpr (TAIL_GLOBAL) {
+                        if (!(RC_B4_ABL & 2)) tail_st(tsc + T * (q0 + q) + (unsigned)tt, nt);
+                        else if (nt.x == 1.2345f) stg2(tsc, to_f2(nt));  // (keeps nt alive)
+                    }
+                    else tail[q0 + q] = nt;
+                }
+            }
+        }
+        stp.mark(10);
+    }
+#if RC_STAMP
+    if ((tid & 63) == 0 && p.spec) {
+        unsigned *dbg = (unsigned *)p.spec + ((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * 32;
+        for (int i = 0; i < 32; ++i) dbg[i] = stp.acc[i];
+    }
+#endif
+}
+
+template <int R>
+hipError_t launch_big4_r(const HopParams &p, hipStream_t s) {
+    const dim3 grid(p.runs_per_channel * p.n_channels), block(BIG4_T);
+    const size_t lds = sizeof(float2) * (size_t)big4_lds_float2(R);
+    const bool hann = p.hann_rot != nullptr;
+    if (p.pitch == 1 && hann) hipLaunchKernelGGL((big4_kernel<R, true, true>), grid, block, lds, s, p);
+    else if (p.pitch == 1) hipLaunchKernelGGL((big4_kernel<R, true, false>), grid, block, lds, s, p);
+    else if (hann) hipLaunchKernelGGL((big4_kernel<R, false, true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((big4_kernel<R, false, false>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_big4(int log2n, const HopParams &p, hipStream_t s) {
+    if (log2n == 15) return launch_big4_r<32>(p, s);
+    if (log2n == 16) return launch_big4_r<64>(p, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace rc

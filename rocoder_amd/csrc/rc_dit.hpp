@@ -1,0 +1,309 @@
+// Packed DIT butterflies, the in-register (j, M - j) pair stage and the computed hanning window / envelope
+// constants shared by the N = 16384 kernels (rc_hop16k.hip) and the fused large-window kernel (rc_big4.hip).
+#pragma once
+#include "rc_dev.hpp"
+
+namespace rc {
+namespace {
+
+// ---- asm-free packed butterflies: plain vector code, hipcc picks the op_sel / neg / inline-constant
+// forms itself (no inline-asm boundary pads, free scheduling).
+//   DIT: r = a + w b = fma(b.yx, w2, fma(b, w.xx, a)),  w2 = (-w.y, w.y)   [conj: w2 = (w.y, -w.y)]
+//        o = a - w b = 2a - r
+__device__ __forceinline__ void vdit(v2f a, v2f b, v2f w, v2f w2, v2f &r, v2f &o) {
+    const v2f t = __builtin_elementwise_fma(b, __builtin_shufflevector(w, w, 0, 0), a);
+    r = __builtin_elementwise_fma(__builtin_shufflevector(b, b, 1, 0), w2, t);
+    const v2f two = {2.0f, 2.0f};
+    o = __builtin_elementwise_fma(a, two, -r);
+}
+__device__ __forceinline__ v2f vcmul(v2f a, v2f k) {  // a * k
+    const v2f t = __builtin_shufflevector(a, a, 0, 0) * k;
+    return __builtin_elementwise_fma(__builtin_shufflevector(a, a, 1, 1), v2f{-k.y, k.x}, t);
+}
+
+// DIT stages S_LO..S_HI on NREG registers: register bit (s - REG_LO) <-> position bit s; the
+// position bits below REG_LO are the runtime value l (< 2^REG_LO; HAS_L = false means l == 0).
+//   a' = a + w b, b' = a - w b, w = exp(-2 pi i (p mod 2^s) / 2^(s+1))   (conjugated when CONJ)
+// butterfly with the twiddle w' = -i w (the second half of a stage's twiddles is the first half
+// rotated by -i): alpha = w.y, beta = -w.x, so only w2r = w.xx * (-sgn) is needed, no complex product
+__device__ __forceinline__ void vdit_rot(v2f a, v2f b, v2f w, v2f w2r, v2f &r, v2f &o) {
+    const v2f t = __builtin_elementwise_fma(b, __builtin_shufflevector(w, w, 1, 1), a);
+    r = __builtin_elementwise_fma(__builtin_shufflevector(b, b, 1, 0), w2r, t);
+    const v2f two = {2.0f, 2.0f};
+    o = __builtin_elementwise_fma(a, two, -r);
+}
+
+// wfine = W_{2^(S_HI+1)}^l, the base twiddle of the last stage; the base of stage s - 1 is the
+// square of the base of stage s (no table loads inside the hop loop: a global load waited on in
+// place costs its full latency, and vmcnt retires in order behind the output stores).
+__device__ __forceinline__ v2f xld(const float2 *lds, int idx) { return to_v(lds[idx]); }
+// Runtime-twiddle butterflies with the (-w.y, w.y) / (w.x, -w.x) operand expressed as VOP3P source
+// modifiers (op_sel + neg_lo / neg_hi): hipcc does not fold a per-lane negation into the modifiers, so
+// the plain-C++ form needs one v_pk_mul per twiddle and form (124 per hop) to build those operands.
+#ifndef RC_ASMNEG
+#define RC_ASMNEG 1
+#endif
+//   r = a + w b (CONJ: a + conj(w) b), o = 2a - r
+template <bool CONJ>
+__device__ __forceinline__ void vdit_m(v2f a, v2f b, v2f w, v2f &r, v2f &o) {
+    const v2f t = __builtin_elementwise_fma(b, __builtin_shufflevector(w, w, 0, 0), a);
+    if (CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(b), "v"(w), "v"(t));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(b), "v"(w), "v"(t));
+    const v2f two = {2.0f, 2.0f};
+    o = __builtin_elementwise_fma(a, two, -r);
+}
+//   the same with the twiddle -i w (CONJ: +i conj(w))
+template <bool CONJ>
+__device__ __forceinline__ void vdit_rot_m(v2f a, v2f b, v2f w, v2f &r, v2f &o) {
+    const v2f t = __builtin_elementwise_fma(b, __builtin_shufflevector(w, w, 1, 1), a);
+    if (CONJ) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(b), "v"(w), "v"(t));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(b), "v"(w), "v"(t));
+    const v2f two = {2.0f, 2.0f};
+    o = __builtin_elementwise_fma(a, two, -r);
+}
+template <int NREG, int M_LOG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L>
+__device__ __forceinline__ void dit_stages(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f}) {
+    if (RC_ABLATE & 8) return;
+    const v2f sgn = CONJ ? v2f{1.0f, -1.0f} : v2f{-1.0f, 1.0f};
+    v2f bases[S_HI - S_LO + 1];
+    if (HAS_L) {
+        bases[S_HI - S_LO] = wfine;
+#pragma unroll
+        for (int s = S_HI - 1; s >= S_LO; --s) bases[s - S_LO] = vcmul(bases[s + 1 - S_LO], bases[s + 1 - S_LO]);
+    }
+#pragma unroll
+    for (int s = S_LO; s <= S_HI; ++s) {
+        const int rb = s - REG_LO;
+        const int half = 1 << rb;
+        if (!HAS_L) {
+#pragma unroll
+            for (int q0 = 0; q0 < NREG; ++q0) {
+                if (q0 & half) continue;
+                const int q1 = q0 | half;
+                const int c = q0 & (half - 1);
+                const int kidx = c * (16 >> rb);  // exp(-2 pi i c / 2^(rb+1)) = W32^kidx
+                const v2f a = v[q0], b = v[q1];
+                const v2f kc = {W32_RE[kidx & 15], W32_IM[kidx & 15]};
+                if (c == 0) {
+                    v[q0] = a + b;
+                    v[q1] = a - b;
+                } else if (kidx == 8) {  // w b = -i b (forward) / +i b (inverse) = -(b.yx * sgn)
+                    const v2f ib = __builtin_shufflevector(b, b, 1, 0) * sgn;
+                    v[q0] = a - ib;
+                    v[q1] = a + ib;
+                } else {
+                    const v2f w2 = v2f{kc.y, kc.y} * sgn;
+                    vdit(a, b, kc, w2, v[q0], v[q1]);
+                }
+            }
+        } else {
+            const v2f base = bases[s - S_LO];  // W_{2^(s+1)}^l
+            // twiddles of the first half of the stage (c < half/2); the rest are these times -i
+            constexpr int NCMAX = NREG / 4 > 0 ? NREG / 4 : 1;
+            const int nc = half > 1 ? half / 2 : 1;
+            v2f tw[NCMAX], tw2[NCMAX], twr[NCMAX];
+#pragma unroll
+            for (int c = 0; c < NCMAX; ++c) {
+                if (c >= nc) continue;
+                const int kidx = c * (16 >> rb);
+                const v2f kc = {W32_RE[kidx & 15], W32_IM[kidx & 15]};
+                tw[c] = c == 0 ? base : vcmul(base, kc);
+                if (!RC_ASMNEG) {
+                    tw2[c] = __builtin_shufflevector(tw[c], tw[c], 1, 1) * sgn;
+                    twr[c] = __builtin_shufflevector(tw[c], tw[c], 0, 0) * (-sgn);
+                }
+            }
+#pragma unroll
+            for (int q0 = 0; q0 < NREG; ++q0) {
+                if (q0 & half) continue;
+                const int q1 = q0 | half;
+                const int c = q0 & (half - 1);
+                const v2f a = v[q0], b = v[q1];
+                if (RC_ASMNEG) {
+                    if (c < nc) vdit_m<CONJ>(a, b, tw[c], v[q0], v[q1]);
+                    else vdit_rot_m<CONJ>(a, b, tw[c - nc], v[q0], v[q1]);
+                } else {
+                    if (c < nc) vdit(a, b, tw[c], tw2[c], v[q0], v[q1]);
+                    else vdit_rot(a, b, tw[c - nc], twr[c - nc], v[q0], v[q1]);
+                }
+            }
+        }
+    }
+}
+
+// one (ja, M - ja) pair entirely in registers; x1 = ja * mul + k0 (phase counter of bin ja)
+template <int LOG2N>
+__device__ __forceinline__ void pair_regs(float2 A, float2 Bp, float2 w, uint32_t x1, PhaseKey key,
+                                          float2 &VA, float2 &VB, bool dc = false) {
+    constexpr uint32_t N = 1u << LOG2N, M = N / 2;
+    const uint32_t cM = M * key.mul + 2u * key.k0;
+    const float nkappa = -0.25f / (float)N;
+    float2 X1, X2c;
+    pair_analyze(A, Bp, w, X1, X2c);
+    const float m1 = cabs_fast(X1) * nkappa, m2 = cabs_fast(X2c) * nkappa;
+    float c1, s1, c2, s2, c3, s3, c4, s4;
+    phase_ncs2_x(x1, c1, s1, c4, s4);       // bins ja and M + ja
+    phase_ncs2_x(cM - x1, c3, s3, c2, s2);  // bins M - ja and N - ja
+    if (dc) {  // ja == 0 wraps: N - 0 is bin 0 again, M - 0 is bin M
+        c2 = c1, s2 = s1;
+        c3 = c4, s3 = s4;
+    }
+    const float px = m1 * (c1 + c2), py = m1 * (s1 - s2);
+    const float qx = m2 * (c3 + c4), qy = m2 * (s4 - s3);
+    const float sx = px + qx, sy = py + qy, rx = px - qx, ry = py - qy;
+    const float ux = rx * w.x + ry * w.y, uy = ry * w.x - rx * w.y;
+    VA = make_float2(sx - uy, sy + ux);
+    VB = make_float2(sx + uy, ux - sy);
+}
+
+// The same pair in packed (re,im) arithmetic: 17 v_pk_* + 10 transcendental + the two hashes instead
+// of ~50 scalar VALU ops. A wave issues one VALU instruction per ~4.75 cycles whatever it is, so the
+// instruction count, not the flop count, sets the middle stage's time (profiles/r01e stamps).
+#ifndef RC_PAIR_PK
+#define RC_PAIR_PK 1
+#endif
+__device__ __forceinline__ void phase_cs2_x(uint32_t x, v2f &lo, v2f &up) {
+    float a, b, c, d;
+    phase_ncs2_x(x, a, b, c, d);
+    lo = v2f{a, b};
+    up = v2f{c, d};
+}
+__device__ __forceinline__ v2f vsel(bool c, v2f a, v2f b) { return v2f{c ? a.x : b.x, c ? a.y : b.y}; }
+// dc (lane predicate): this lane's pair is bin 0 with itself - N - 0 is bin 0 again and M - 0 is bin M, so the
+// phases of "N - ja" and "M - ja" are those of bins ja and M + ja (only ever true for one lane of one slot)
+template <int LOG2N, bool DC = false>
+__device__ __forceinline__ void pair_regs_pk(v2f A, v2f Bp, v2f w, uint32_t x1, PhaseKey key, v2f &VA,
+                                             v2f &VB, bool dc = false) {
+    constexpr uint32_t N = 1u << LOG2N, M = N / 2;
+    const uint32_t cM = M * key.mul + 2u * key.k0;
+    const float nkappa = -0.25f / (float)N;
+    const v2f cj = {1.0f, -1.0f}, jc = {-1.0f, 1.0f};
+    const v2f Bc = Bp * cj;                                    // conj(Bp)
+    const v2f E = A + Bc, D = A - Bc;                          // 2E, 2D
+    const v2f T = vcmul(D, w);                                 // T = w D
+    // U = (X1.x, X2c.x) = (ex + ty, ex - ty), V = (X1.y, X2c.y) = (ey - tx, ey + tx)
+    const v2f U = __builtin_shufflevector(E, E, 0, 0) + __builtin_shufflevector(T, T, 1, 1) * cj;
+    const v2f V = __builtin_shufflevector(E, E, 1, 1) + __builtin_shufflevector(T, T, 0, 0) * jc;
+    const v2f q2 = __builtin_elementwise_fma(V, V, U * U);     // (|X1|^2, |X2c|^2)
+    const v2f mm = v2f{__builtin_amdgcn_sqrtf(q2.x), __builtin_amdgcn_sqrtf(q2.y)} * v2f{nkappa, nkappa};
+    v2f cs1, cs2, cs3, cs4;
+    phase_cs2_x(x1, cs1, cs4);       // bins ja and M + ja
+    phase_cs2_x(cM - x1, cs3, cs2);  // bins M - ja and N - ja
+    if (DC) {
+        cs2 = vsel(dc, cs1, cs2);
+        cs3 = vsel(dc, cs4, cs3);
+    }
+    const v2f P0 = cs1 + cs2 * cj;   // (c1 + c2, s1 - s2)
+    const v2f Q0 = cs4 + cs3 * cj;   // (c4 + c3, s4 - s3)
+    const v2f m1 = __builtin_shufflevector(mm, mm, 0, 0), m2 = __builtin_shufflevector(mm, mm, 1, 1);
+    const v2f Pz = P0 * m1;
+    const v2f S = __builtin_elementwise_fma(Q0, m2, Pz);
+    const v2f R = __builtin_elementwise_fma(Q0, -m2, Pz);
+    // Uc = conj(w) R = (rx wx + ry wy, ry wx - rx wy)
+    const v2f t0 = R * __builtin_shufflevector(w, w, 0, 0);
+    const v2f Uc = __builtin_elementwise_fma(__builtin_shufflevector(R, R, 1, 0),
+                                             __builtin_shufflevector(w, w, 1, 1) * cj, t0);
+    const v2f Us = __builtin_shufflevector(Uc, Uc, 1, 0);      // (uy, ux)
+    VA = S + Us * jc;                                          // (sx - uy, sy + ux)
+    VB = Us + S * cj;                                          // (sx + uy, ux - sy)
+}
+
+// hop4's variant of the pair: the same algebra with (a) the 1/(4N) scale left out (hop4 folds it into the
+// synthesis window constants - an exact power of two), (b) the two complex products written with VOP3P
+// source modifiers instead of materialised (-w.y, w.x) / (w.y, -w.y) operands.
+//   cmul_fma(a, w, t)   = t + a.yy * (-w.y, w.x)      -> with t = a.xx * w this is a * w
+//   cmulc_fma(a, w, t)  = t + a.yx * (w.y, -w.y)      -> with t = a * w.xx this is a * conj(w)
+__device__ __forceinline__ v2f cmul_fma(v2f a, v2f w, v2f t) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ v2f cmulc_fma(v2f a, v2f w, v2f t) {
+    v2f r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// BAND: gq = the gains of bins ja and M - ja (the curated band-mask kernel RC_DK_BAND, fused: |g X| = |g| |X|)
+template <int LOG2N, bool DC = false, bool BAND = false>
+__device__ __forceinline__ void pair_regs_pk4(v2f A, v2f Bp, v2f w, uint32_t x1, PhaseKey key, v2f &VA,
+                                              v2f &VB, bool dc = false, v2f gq = v2f{1.0f, 1.0f}) {
+    constexpr uint32_t N = 1u << LOG2N, M = N / 2;
+    const uint32_t cM = M * key.mul + 2u * key.k0;
+    const v2f cj = {1.0f, -1.0f}, jc = {-1.0f, 1.0f};
+    const v2f Bc = Bp * cj;                                    // conj(Bp) (fused into E, D by the compiler)
+    const v2f E = A + Bc, D = A - Bc;                          // 2E, 2D
+    const v2f T = cmul_fma(D, w, __builtin_shufflevector(D, D, 0, 0) * w);  // T = w D
+    const v2f U = __builtin_shufflevector(E, E, 0, 0) + __builtin_shufflevector(T, T, 1, 1) * cj;
+    const v2f V = __builtin_shufflevector(E, E, 1, 1) + __builtin_shufflevector(T, T, 0, 0) * jc;
+    const v2f q2 = __builtin_elementwise_fma(V, V, U * U);     // (|X1|^2, |X2c|^2)
+    v2f mm = v2f{__builtin_amdgcn_sqrtf(q2.x), __builtin_amdgcn_sqrtf(q2.y)};
+    if constexpr (BAND) mm = mm * gq;
+    v2f cs1, cs2, cs3, cs4;
+    phase_cs2_x(x1, cs1, cs4);       // bins ja and M + ja
+    phase_cs2_x(cM - x1, cs3, cs2);  // bins M - ja and N - ja
+    if (DC) {
+        cs2 = vsel(dc, cs1, cs2);
+        cs3 = vsel(dc, cs4, cs3);
+    }
+    const v2f P0 = cs1 + cs2 * cj;   // (c1 + c2, s1 - s2)
+    const v2f Q0 = cs4 + cs3 * cj;   // (c4 + c3, s4 - s3)
+    const v2f m1 = __builtin_shufflevector(mm, mm, 0, 0), m2 = __builtin_shufflevector(mm, mm, 1, 1);
+    const v2f Pz = P0 * m1;
+    const v2f S = __builtin_elementwise_fma(Q0, m2, Pz);
+    const v2f R = __builtin_elementwise_fma(Q0, -m2, Pz);
+    const v2f Uc = cmulc_fma(R, w, R * __builtin_shufflevector(w, w, 0, 0));  // conj(w) R
+    const v2f Us = __builtin_shufflevector(Uc, Uc, 1, 0);      // (uy, ux)
+    VA = S + Us * jc;                                          // (sx - uy, sy + ux)
+    VB = Us + S * cj;                                          // (sx + uy, ux - sy)
+}
+
+// ---- default-window fast path: windows::hanning (src/windows.rs:4-9) and the crossfade envelope
+// (src/crossfade.rs:4-10) are both 0.5 - c cos(2 pi i / (len - 1)). Thread t touches samples
+// i = 512 q + 2 t + e, so cos(alpha_q + beta_te) = cos alpha_q cos beta_te - sin alpha_q sin beta_te:
+// the 32 (16) alpha terms are compile-time constants, the beta terms 4 (+4) floats per thread from
+// HopParams::hann_rot. Two FMAs per sample replace a table load (the loads were 70 % of the
+// kernel's vector-memory traffic).
+constexpr double cx_sin_taylor(double x) {  // |x| <= pi/2
+    double term = x, sum = x;
+    for (int n = 1; n < 16; ++n) {
+        term *= -x * x / ((2.0 * n) * (2.0 * n + 1.0));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double CX_PI = 3.14159265358979323846264338327950288;
+constexpr double cx_sin(double x) {  // 0 <= x < 2 pi + eps
+    while (x > CX_PI) x -= 2.0 * CX_PI;
+    if (x > CX_PI / 2) x = CX_PI - x;
+    if (x < -CX_PI / 2) x = -CX_PI - x;
+    return cx_sin_taylor(x);
+}
+constexpr double cx_cos(double x) { return cx_sin(x + CX_PI / 2); }
+struct HannK {
+    float c[32], s[32];
+};
+// c[q] = -amp cos(2 pi 512 q / (len - 1)), s[q] = amp sin(...): value(i) = 0.5 + c[q] cb + s[q] sb
+constexpr HannK make_hann_k(double amp, int len, int count) {
+    HannK k{};
+    for (int q = 0; q < 32; ++q) {
+        const double a = q < count ? 2.0 * CX_PI * 512.0 * q / (double)(len - 1) : 0.0;
+        k.c[q] = (float)(-amp * cx_cos(a));
+        k.s[q] = (float)(amp * cx_sin(a));
+    }
+    return k;
+}
+constexpr double cx_sqrt(double x) {
+    double r = x > 1 ? x : 1.0;
+    for (int i = 0; i < 64; ++i) r = 0.5 * (r + x / r);
+    return r;
+}
+constexpr double HANN_ENV_AMP = 1.0 - (1.0 + cx_sqrt(cx_sqrt(0.5))) * 0.5;  // crossfade.rs:5
+__device__ constexpr HannK HANN_W14 = make_hann_k(0.5, 16384, 32);
+__device__ constexpr HannK HANN_E14 = make_hann_k(HANN_ENV_AMP, 8192, 16);
+// synthesis window times -1/(4N) = -2^-16 (hop4: the scale of the magnitudes, src/fft.rs:72's / N and the sign
+// of the negated phasors, moved out of the per-bin stage; a power of two, so nothing rounds differently)
+constexpr double HANN_KAPPA = -0.25 / 16384.0;
+__device__ constexpr HannK HANN_W14K = make_hann_k(0.5 * HANN_KAPPA, 16384, 32);
+
+}  // namespace
+}  // namespace rc

@@ -196,7 +196,9 @@ struct rc_engine {
     // device -> host error word (pinned, mapped): a kernel that gives up (seam wait expired) leaves a
     // code here; the next API call reports it as RC_EHIP
     uint32_t *h_err = nullptr, *d_err = nullptr;
-    uint32_t diag_flags = 0;  // ROCODER_DIAG (tests only)
+    uint32_t diag_flags = 0;  // ROCODER_DIAG: read only by the test-hook library (RC_TEST_HOOKS), else always 0
+    // run-planner overrides (tuning tools; test-hook library only, read once at create): 0 = the defaults
+    int tune_rounds = 0, tune_min_run = 0, tune_b4_rounds = 0;
     std::vector<float> h_spec, h_spec2;
     bool tail_zeroed = false;
     // user-kernel path: a stateful apply() forbids recomputing hops, so the overlap tail is carried
@@ -258,16 +260,14 @@ void plan_runs(const rc_engine *e, uint32_t n_channels, int64_t hop_count, uint3
         // (tools/ab_rounds.py) 4 / 6 / 8 / 12 rounds = 1.434 / 1.422 / 1.423 / 1.421 ms; shorter runs (min_run 4) lose
         // to the seam hand-overs again
         rounds = 4 * RC_ROUNDS;
-        const int env_rounds = getenv("ROCODER_ROUNDS") ? atoi(getenv("ROCODER_ROUNDS")) : 0;  // tuning
-        if (env_rounds > 0) rounds = (uint32_t)env_rounds;
+        if (e->tune_rounds > 0) rounds = (uint32_t)e->tune_rounds;
     }
 #ifdef RC_WG_PER_CU
     wg_per_cu = RC_WG_PER_CU;  // tuning builds
 #endif
     const uint64_t target = (uint64_t)e->n_cu * wg_per_cu * rounds;  // rounds of resident workgroups
     uint64_t r = std::max<uint64_t>(1, target / std::max<uint32_t>(1, n_channels));
-    const int env_min_run = getenv("ROCODER_MIN_RUN") ? atoi(getenv("ROCODER_MIN_RUN")) : 0;  // tuning
-    const int64_t min_run = env_min_run > 0 ? env_min_run : 8;
+    const int64_t min_run = e->tune_min_run > 0 ? e->tune_min_run : 8;
     r = std::min<uint64_t>(r, (uint64_t)std::max<int64_t>(1, hop_count / min_run));
     r = std::max<uint64_t>(r, 1);
     uint64_t len = ((uint64_t)hop_count + r - 1) / r;
@@ -684,14 +684,14 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         p.hop_count = hop_count;
         p.wtab = e->d_wtab_m;
         // one workgroup per CU and launch (measured on C5: 1 / 2 / 3 / 4 / 6 rounds of workgroups = 6.45 / 6.50 / 6.61 /
-        // 6.60 / 6.72 ms: every run recomputes one hop and reloads its tables); ROCODER_B4_ROUNDS overrides (tuning)
-        static const int b4_rounds = getenv("ROCODER_B4_ROUNDS") ? std::max(1, atoi(getenv("ROCODER_B4_ROUNDS"))) : 1;
+        // 6.60 / 6.72 ms: every run recomputes one hop and reloads its tables); ROCODER_B4_ROUNDS overrides it in the test-hook build
+        const int b4_rounds = std::max(1, e->tune_b4_rounds);
         uint64_t r = std::max<uint64_t>(1, (uint64_t)e->n_cu * b4_rounds / n_channels);
         r = std::max<uint64_t>(1, std::min<uint64_t>(r, (uint64_t)hop_count / 8));
         const uint64_t len = ((uint64_t)hop_count + r - 1) / r;
         p.run_len = (uint32_t)len;
         p.runs_per_channel = (uint32_t)(((uint64_t)hop_count + len - 1) / len);
-        if (e->log2n == 16) {  // the carried tail goes through a per-workgroup scratch (rc_kernels.hip)
+        if (e->log2n == 16) {  // the carried tail goes through a per-workgroup scratch (rc_big4.hip)
             if (int rcs = e->d_ybuf.reserve((size_t)p.runs_per_channel * n_channels * H * sizeof(float))) return rcs;
             p.ybuf = (float *)e->d_ybuf.p;
         }
@@ -1044,7 +1044,7 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
     else hanning(N, w.data());                    // src/main.rs:131
     crossfade_comp(H, env.data());                // src/stretcher.rs:56
     // the N = 16384 kernel computes the default window and the envelope in registers instead of
-    // loading them (rc_kernels.hip, HANN); a caller-supplied window gets that path only when it
+    // loading them (rc_hop16k.hip / rc_big4.hip, HANN); a caller-supplied window gets that path only when it
     // is the default one bit for bit
     bool default_window = true;
     if (cfg->window) {
@@ -1116,7 +1116,13 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
     RC_HIP_C(hipHostMalloc((void **)&e->h_err, sizeof(uint32_t), hipHostMallocMapped));
     *e->h_err = 0;
     RC_HIP_C(hipHostGetDevicePointer((void **)&e->d_err, e->h_err, 0));
+#if RC_TEST_HOOKS
+    // test-hook library only (make hooks): the product library reads no diagnostic or tuning variable
     if (const char *diag = getenv("ROCODER_DIAG")) e->diag_flags = (uint32_t)strtoul(diag, nullptr, 0);
+    if (const char *v = getenv("ROCODER_ROUNDS")) e->tune_rounds = atoi(v);
+    if (const char *v = getenv("ROCODER_MIN_RUN")) e->tune_min_run = atoi(v);
+    if (const char *v = getenv("ROCODER_B4_ROUNDS")) e->tune_b4_rounds = atoi(v);
+#endif
     RC_HIP_C(hipMalloc((void **)&e->d_window, N * sizeof(float)));
     RC_HIP_C(hipMalloc((void **)&e->d_env, H * sizeof(float)));
     RC_HIP_C(hipMalloc((void **)&e->d_wtab, wtab.size() * sizeof(float2)));

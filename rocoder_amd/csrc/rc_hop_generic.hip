@@ -1,0 +1,378 @@
+// gfx950 (MI355X / CDNA4) kernels of the rocoder stretch hot path.
+//
+// One workgroup owns a contiguous run of hops of one channel and, per hop k, computes
+//   a_k[n] = x[k*step+n] * w[n]                       (src/fft.rs:51-55)
+//   X_k    = DFT_N(a_k)                                (src/fft.rs:59)      real->complex, N/2-pt
+//   Z_k[j] = |X_k[j]| * e^{i theta(seed,c,k,j)}        (src/fft.rs:65-68)   all N bins drawn
+//   y_k[n] = Re(IDFT_N(Z_k))[n] / N * w[n]             (src/fft.rs:69-73)   complex->real, N/2-pt
+//   O[kH+i] = (y_k[i] + y_{k-1}[H+i]) * env[i] * amp   (src/stretcher.rs:96-103)
+//   F[t]    = O[t*p]                                   (src/stretcher.rs:108-111, resampler.rs:15-18)
+//
+// Layout of one hop inside the workgroup (M = N/2 complex points, T threads, P = M/T
+// register-resident points per thread):
+//   * the N/2-point FFT runs as bit-group passes: each pass transforms up to log2(P) index bits
+//     entirely in registers (radix-2 butterflies with compile-time 32nd roots x one per-thread
+//     base twiddle per stage), passes exchange through LDS (padded 1 complex per 32: conflict-free
+//     ds_read/write_b64 for every pass layout); forward is DIF (natural in, bit-reversed out),
+//     inverse is the mirrored DIT, so no reordering pass exists;
+//   * the real<->complex split, magnitude, random phasors and the Hermitian fold happen on the
+//     bit-reversed spectrum in LDS, a "quad" {j, j+M/2, M/2-j, M-j} per slot;
+//   * the window multiply and the two-term overlap-add stay in registers: a thread's tail samples
+//     of hop k line up with its head samples of hop k+1, so the run carries y_{k-1}[H..] in VGPRs
+//     and the first hop of a run is recomputed (phases are a pure function of (seed,c,k,j)).
+// No MFMA: this is an FFT/SFU/LDS-bound path, not a contraction.
+#include "rc_passes.hpp"
+
+namespace rc {
+namespace {
+
+// pA / pB: padded LDS indices of bins ja and M - ja
+template <int LOG2N, int MODE>
+__device__ __forceinline__ void do_pair(float2 *lds, int pA, int pB, float2 w, uint32_t ja,
+                                        PhaseKey key, GV2W spec) {
+    constexpr uint32_t N = 1u << LOG2N, M = N / 2;
+    float2 VA, VB;
+    if constexpr (MODE == MODE_RESYNTH) {
+        const float m1a = cabs_fast(ldg2(spec + ja));
+        const float m1b = cabs_fast(ldg2(spec + ((N - ja) & (N - 1))));
+        const float m2a = cabs_fast(ldg2(spec + (M - ja)));
+        const float m2b = cabs_fast(ldg2(spec + ((M + ja) & (N - 1))));
+        pair_synth<LOG2N>(m1a, m1b, m2a, m2b, w, ja, key, -0.5f / (float)N, VA, VB);
+        lds[pA] = VA;
+        if (pB != pA) lds[pB] = VB;
+    } else {
+        const float2 A = lds[pA];
+        const float2 Bp = lds[pB];
+        float2 X1, X2c;
+        pair_analyze(A, Bp, w, X1, X2c);
+        if constexpr (MODE == MODE_FORWARD) {
+            const float2 x1 = make_float2(0.5f * X1.x, 0.5f * X1.y);
+            const float2 x2 = make_float2(0.5f * X2c.x, 0.5f * X2c.y);
+            stg2(spec + ja, x1);                                                       // X[ja]
+            stg2(spec + ((N - ja) & (N - 1)), make_float2(x1.x, ja ? -x1.y : x1.y));   // X[N-ja]
+            stg2(spec + (M - ja), make_float2(x2.x, -x2.y));                           // X[M-ja]
+            stg2(spec + ((M + ja) & (N - 1)), ja ? x2 : make_float2(x2.x, -x2.y));     // X[M+ja]
+        } else {
+            const float m1 = cabs_fast(X1), m2 = cabs_fast(X2c);
+            pair_synth<LOG2N>(m1, m1, m2, m2, w, ja, key, -0.25f / (float)N, VA, VB);
+            lds[pA] = VA;
+            if (pB != pA) lds[pB] = VB;
+        }
+    }
+}
+
+// Middle stage on the bit-reversed spectrum in LDS (position p holds bin brev_m(p)).
+template <int LOG2N, int MODE>
+__device__ __forceinline__ void middle_stage(float2 *lds, int tid, PhaseKey key,
+                                             GV2 rtab, GV2W spec) {
+    using G = Geo<LOG2N>;
+    constexpr int m = G::m, M = G::M;
+    opaque(tid);  // slot addresses / twiddles are recomputed per hop instead of living in VGPRs
+#pragma unroll
+    for (int s = 0; s < G::QN; ++s) {
+        const int c = tid + G::T * s;
+        if (c == 0) continue;  // slot 0 is the special block below
+        const int j = (int)(__brev((unsigned)(2 * c)) >> (32 - (m - 1)));  // bin in (0, M/4)
+        const int j2 = M / 2 - j;
+        const int p1 = 4 * c;                                              // brev_m(j)
+        const int p2 = (int)(__brev((unsigned)j2) >> (32 - m));            // brev_m(M/2 - j)
+        const float2 w = ldg2(rtab + j);
+        // pair (j, M-j): positions p1, p2+1 ; pair (M/2-j, M/2+j): positions p2, p1+1
+        do_pair<LOG2N, MODE>(lds, pad_idx(p1), pad_idx(p2 + 1), w, (uint32_t)j, key, spec);
+        do_pair<LOG2N, MODE>(lds, pad_idx(p2), pad_idx(p1 + 1), make_float2(-w.y, -w.x),
+                             (uint32_t)j2, key, spec);
+    }
+    if (tid == 0) {
+        // bins 0 (+Nyquist) at position 0, M/2 at position 1, pair (M/4, 3M/4) at 2, 3
+        do_pair<LOG2N, MODE>(lds, 0, 0, make_float2(1.f, 0.f), 0u, key, spec);
+        do_pair<LOG2N, MODE>(lds, 1, 1, make_float2(0.f, -1.f), (uint32_t)(M / 2), key, spec);
+        do_pair<LOG2N, MODE>(lds, 2, 3, ldg2(rtab + M / 4), (uint32_t)(M / 4), key, spec);
+    }
+}
+
+// Fused-path middle stage, batched: all slot addresses, twiddle loads and LDS reads are issued up
+// front (v[] is dead here, so there are registers to hold them), then the pairs are computed
+// branch-free; thread 0's slot 0 is computed on a harmless stand-in and written to a spare LDS
+// element, the three special pairs follow under one branch.
+template <int LOG2N>
+__device__ __forceinline__ void middle_fused(float2 *lds, int tid, PhaseKey key, GV2 rtab) {
+    using G = Geo<LOG2N>;
+    constexpr int m = G::m, M = G::M, QN = G::QN;
+    constexpr uint32_t N = 2u * M;
+    constexpr int DUMMY = G::LDS_FLOAT2 - 1;
+    opaque(tid);
+    int ia[QN], ib[QN], ic[QN], id[QN];
+    uint32_t ja[QN];
+    float2 w[QN], A1[QN], A2[QN], B1[QN], B2[QN];
+#pragma unroll
+    for (int s = 0; s < QN; ++s) {
+        int c = tid + G::T * s;
+        if (s == 0) c = c ? c : 1;  // thread 0 / slot 0: stand-in, results go to DUMMY
+        const int j = (int)(__brev((unsigned)(2 * c)) >> (32 - (m - 1)));  // bin in (0, M/4)
+        const int p1 = 4 * c;                                              // brev_m(j)
+        const int p2 = (int)(__brev((unsigned)(M / 2 - j)) >> (32 - m));   // brev_m(M/2 - j)
+        ja[s] = (uint32_t)j;
+        w[s] = ldg2(rtab + j);
+        ia[s] = pad_idx(p1);
+        ib[s] = pad_idx(p1 + 1);
+        ic[s] = pad_idx(p2);
+        id[s] = pad_idx(p2 + 1);
+    }
+#pragma unroll
+    for (int s = 0; s < QN; ++s) {
+        A1[s] = lds[ia[s]];  // bin j
+        A2[s] = lds[ib[s]];  // bin j + M/2
+        B1[s] = lds[ic[s]];  // bin M/2 - j
+        B2[s] = lds[id[s]];  // bin M - j
+    }
+    if (tid == 0) {  // redirect the stand-in's writes (uniform per wave except wave 0)
+        ia[0] = ib[0] = ic[0] = id[0] = DUMMY;
+    }
+    // the two counters of a pair follow from one multiply: x(b) = b*mul + k0 serves bins b and
+    // M + b, x(M-b) = (M*mul + 2 k0) - x(b) serves bins M - b and N - b
+    const uint32_t cM = M * key.mul + 2u * key.k0;
+    const float nkappa = -0.25f / (float)N;
+#pragma unroll
+    for (int s = 0; s < QN; ++s) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // h = 0: pair (j, M-j) = (A1, B2), twiddle w ; h = 1: pair (M/2-j, M/2+j) = (B1, A2),
+            // twiddle -i conj(w)
+            const float2 A = h ? B1[s] : A1[s];
+            const float2 Bp = h ? A2[s] : B2[s];
+            const float2 ww = h ? make_float2(-w[s].y, -w[s].x) : w[s];
+            const uint32_t jb = h ? (uint32_t)(M / 2) - ja[s] : ja[s];
+            float2 X1, X2c;
+            pair_analyze(A, Bp, ww, X1, X2c);
+            float m1 = cabs_fast(X1) * nkappa, m2 = cabs_fast(X2c) * nkappa;
+            const uint32_t x1 = jb * key.mul + key.k0;
+            float c1, s1, c2, s2, c3, s3, c4, s4;
+            phase_ncs2_x(x1, c1, s1, c4, s4);       // bins jb and M + jb
+            phase_ncs2_x(cM - x1, c3, s3, c2, s2);  // bins M - jb and N - jb
+            const float px = m1 * (c1 + c2), py = m1 * (s1 - s2);  // Zs[jb]
+            const float qx = m2 * (c3 + c4), qy = m2 * (s4 - s3);  // conj(Zs[M-jb])
+            const float sx = px + qx, sy = py + qy;
+            const float rx = px - qx, ry = py - qy;
+            const float ux = rx * ww.x + ry * ww.y, uy = ry * ww.x - rx * ww.y;  // U = conj(w) R
+            const float2 VA = make_float2(sx - uy, sy + ux);  // S + iU        -> bin jb
+            const float2 VB = make_float2(sx + uy, ux - sy);  // conj(S - iU)  -> bin M - jb
+            if (h == 0) {
+                lds[ia[s]] = VA;
+                lds[id[s]] = VB;
+            } else {
+                lds[ic[s]] = VA;
+                lds[ib[s]] = VB;
+            }
+        }
+    }
+    if (tid == 0) {
+        // bins 0 (+Nyquist) at position 0, M/2 at position 1, pair (M/4, 3M/4) at 2, 3
+        do_pair<LOG2N, MODE_FUSED>(lds, 0, 0, make_float2(1.f, 0.f), 0u, key, (GV2W) nullptr);
+        do_pair<LOG2N, MODE_FUSED>(lds, 1, 1, make_float2(0.f, -1.f), (uint32_t)(M / 2), key,
+                                   (GV2W) nullptr);
+        do_pair<LOG2N, MODE_FUSED>(lds, 2, 3, ldg2(rtab + M / 4), (uint32_t)(M / 4), key,
+                                   (GV2W) nullptr);
+    }
+}
+
+template <int LOG2N, int MODE, bool PITCH1>
+__global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(const HopParams p) {
+    using G = Geo<LOG2N>;
+    constexpr int P = G::P, T = G::T, M = G::M, N = G::N, H = M;
+    constexpr int LL = last_lor<G>(G::m);
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    ThreadCtx<G> ctx;
+    ctx.tid = threadIdx.x;
+    fill_lds_bases<G, G::m>(ctx);
+    const int tid = ctx.tid;
+    const uint32_t run = blockIdx.x % p.runs_per_channel;
+    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
+    int64_t k_end = k_begin + p.run_len;
+    if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
+    if (k_begin >= k_end) return;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    const unsigned lane2 = 2u * (unsigned)tid;
+    GV2 wtab = (GV2)p.wtab;
+    GV2 rtab = (GV2)p.rtab;
+
+    float2 v[P];
+    Stamps st;
+    st.init();
+    if constexpr (MODE == MODE_FORWARD) {
+        for (int64_t k = k_begin; k < k_end; ++k) {
+            GV2W spec = (GV2W)p.spec + ((size_t)ch * p.hop_count + (size_t)(k - p.hop_first)) * N;
+            load_hop<LOG2N>(v, p, xc, xt, per_hop(p.window), k, lane2);
+            forward_passes<G, G::m, 0, true>(v, lds, ctx, wtab, st);
+            lds_store<G, LL>(v, lds, ctx.lb[LL]);
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            middle_stage<LOG2N, MODE_FORWARD>(lds, tid, PhaseKey{0u, 1u}, rtab, spec);
+            if (!(RC_ABLATE & 4)) __syncthreads();
+        }
+    } else if constexpr (MODE == MODE_RESYNTH) {
+        for (int64_t k = k_begin; k < k_end; ++k) {
+            const size_t hop_idx = (size_t)ch * p.hop_count + (size_t)(k - p.hop_first);
+            GV2W spec = (GV2W)p.spec + hop_idx * N;
+            const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+            middle_stage<LOG2N, MODE_RESYNTH>(lds, tid, key, rtab, spec);
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            lds_load<G, LL>(v, lds, ctx.lb[LL]);
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            inverse_passes<G, G::m>(v, lds, ctx, wtab, st);
+            GFW y = (GFW)p.ybuf + hop_idx * N;
+            GF wsrc = per_hop(p.window);
+            constexpr int CH = P < RC_LOADCH ? P : RC_LOADCH;
+#pragma unroll
+            for (int q0 = 0; q0 < P; q0 += CH) {
+#pragma unroll
+                for (int q = q0; q < q0 + CH; ++q)
+                    stg2((GV2W)(y + 2 * T * q + lane2),
+                         make_float2(v[q].x * (wsrc + 2 * T * q)[lane2],
+                                     v[q].y * (wsrc + 2 * T * q)[lane2 + 1]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+        // fused path: overlap-add in registers. head slot q' <-> tail slot q' + P/2.
+        constexpr int PH = P / 2;
+        float2 tail[PH];
+#pragma unroll
+        for (int q = 0; q < PH; ++q) tail[q] = make_float2(0.f, 0.f);
+        GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
+        const uint32_t pitch = PITCH1 ? 1u : p.pitch;
+        // hop k_begin - 1 is recomputed only for its tail (global hop 0 has a zero predecessor:
+        // src/stretcher.rs:58-59)
+        for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
+            const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+            load_hop<LOG2N>(v, p, xc, xt, per_hop(p.window), k, lane2);
+            st.mark(0);
+            forward_passes<G, G::m, 0, true>(v, lds, ctx, wtab, st);
+            lds_store<G, LL>(v, lds, ctx.lb[LL]);
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            st.mark(12);
+            if (!(RC_ABLATE & 16)) middle_fused<LOG2N>(lds, tid, key, rtab);
+            st.mark(13);
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            st.mark(14);
+            lds_load<G, LL>(v, lds, ctx.lb[LL]);
+            if (!(RC_ABLATE & 4)) __syncthreads();
+            st.mark(15);
+            inverse_passes<G, G::m>(v, lds, ctx, wtab, st);
+            {
+                // window loads for the synthesis multiply: all issued, one wait
+                GF wsrc = per_hop(p.window);
+                float wr0[P], wr1[P];
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    wr0[q] = (wsrc + 2 * T * q)[lane2];
+                    wr1[q] = (wsrc + 2 * T * q)[lane2 + 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < P; ++q) v[q] = make_float2(v[q].x * wr0[q], v[q].y * wr1[q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            st.mark(27);
+            if ((RC_ABLATE & 2) ? (v[0].x == 1.2345f) : (k >= k_begin)) {
+                const int64_t g0 = k * (int64_t)H;  // absolute O index of this hop's first sample
+                GF esrc = per_hop(p.env);
+                if constexpr (PITCH1) {
+                    GFW dst = outc + (g0 - p.out_origin);
+                    float er0[PH], er1[PH];
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) {
+                        er0[q] = (esrc + 2 * T * q)[lane2];
+                        er1[q] = (esrc + 2 * T * q)[lane2 + 1];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) {
+                        float2 o;  // stretcher.rs:97-100 operation order
+                        o.x = (v[q].x + tail[q].x) * er0[q] * p.amp;
+                        o.y = (v[q].y + tail[q].y) * er1[q] * p.amp;
+                        stg2((GV2W)(dst + 2 * T * q + lane2), o);
+                    }
+                } else {
+                    // F[t] = O[t p]: keep element g = g0 + i iff g % p == 0, at F[g / p]
+                    const int64_t kq = g0 / pitch;
+                    const uint32_t kr = (uint32_t)(g0 % pitch);
+                    GFW dst = outc + (kq - p.out_origin);
+                    int t2 = tid;
+                    opaque(t2);
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) {
+                        const uint32_t i0 = 2u * (uint32_t)(t2 + T * q);
+                        const float o0 = (v[q].x + tail[q].x) * (esrc + 2 * T * q)[lane2] * p.amp;
+                        const float o1 = (v[q].y + tail[q].y) * (esrc + 2 * T * q)[lane2 + 1] * p.amp;
+                        const uint32_t a0 = kr + i0, a1 = a0 + 1;
+                        const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
+                        if (d0 * pitch == a0) dst[d0] = o0;
+                        if (d1 * pitch == a1) dst[d1] = o1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PH; ++q) tail[q] = v[q + PH];
+            st.mark(28);
+        }
+#if RC_STAMP
+        if ((tid & 63) == 0 && p.spec) {
+            unsigned *dbg = (unsigned *)p.spec + ((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * 32;
+            for (int i = 0; i < 32; ++i) dbg[i] = st.acc[i];
+        }
+#endif
+    }
+}
+
+template <int LOG2N>
+hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
+    using G = Geo<LOG2N>;
+    const dim3 grid(p.runs_per_channel * p.n_channels), block(G::T);
+    const size_t lds = sizeof(float2) * G::LDS_FLOAT2;
+    switch (mode) {
+        case MODE_FUSED:
+            if constexpr (LOG2N == 14) return launch_hop16k(p, s);  // hop4_kernel / hop2_kernel (rc_hop16k.hip)
+            else if (p.pitch == 1) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true>), grid, block, lds, s, p);
+            else hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, false>), grid, block, lds, s, p);
+            break;
+        case MODE_FORWARD:
+            hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FORWARD, true>), grid, block, lds, s, p);
+            break;
+        case MODE_RESYNTH:
+            hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_RESYNTH, true>), grid, block, lds, s, p);
+            break;
+    }
+    return hipGetLastError();
+}
+}  // namespace
+
+int hop_workgroups_per_cu(int log2n, bool default_window) {
+    return (log2n == 14 && default_window) ? 3 : 0;  // hop4_kernel: three workgroups per CU
+}
+
+bool hop_geometry(int log2n, int *threads, size_t *lds_bytes) {
+    if (log2n < 5 || log2n > 14) return false;
+    const int m = log2n - 1, M = 1 << m;
+    const int T = cmax(M / RC_PMAX, cmin(64, M / 4));
+    if (threads) *threads = T;
+    if (lds_bytes) *lds_bytes = sizeof(float2) * (size_t)(M + (M >> 5) + 1);
+    return true;
+}
+
+hipError_t launch_hop(int log2n, HopMode mode, const HopParams &p, hipStream_t s) {
+    switch (log2n) {
+        case 5: return launch_hop_n<5>(mode, p, s);
+        case 6: return launch_hop_n<6>(mode, p, s);
+        case 7: return launch_hop_n<7>(mode, p, s);
+        case 8: return launch_hop_n<8>(mode, p, s);
+        case 9: return launch_hop_n<9>(mode, p, s);
+        case 10: return launch_hop_n<10>(mode, p, s);
+        case 11: return launch_hop_n<11>(mode, p, s);
+        case 12: return launch_hop_n<12>(mode, p, s);
+        case 13: return launch_hop_n<13>(mode, p, s);
+        case 14: return launch_hop_n<14>(mode, p, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+}  // namespace rc

@@ -1,5 +1,5 @@
 // Internal interface between the host engine (rc_engine.cpp) and the gfx950 kernels
-// (rc_kernels.hip). Not part of the C-ABI.
+// (rc_*.hip). Not part of the C-ABI.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -137,8 +137,13 @@ constexpr uint32_t RC_ERR_SEAM_TIMEOUT = 1;
 // HopParams::diag_flags (ROCODER_DIAG, tests only): the producer of a seam never publishes its flag
 constexpr uint32_t RC_DIAG_SKIP_SEAM_PUBLISH = 1;
 // run the previous kernel generation of the N = 16384 path (hop3) instead of hop4: A/B timing and the
-// bit-exactness test between the two
+// bit-exactness test between the two. Only the test-hook library (-DRC_TEST_HOOKS=1, `make hooks`) contains it.
 constexpr uint32_t RC_DIAG_PREV_KERNEL = 2;
+// test-hook library only: hop2_kernel's computed-window variant (two workgroups per CU) instead of hop4
+constexpr uint32_t RC_DIAG_HOP2_HANN = 4;
+#ifndef RC_TEST_HOOKS
+#define RC_TEST_HOOKS 0
+#endif
 
 // Geometry chosen by the kernels for a window length (threads per workgroup, LDS bytes).
 bool hop_geometry(int log2n, int *threads, size_t *lds_bytes);
@@ -147,6 +152,9 @@ bool hop_geometry(int log2n, int *threads, size_t *lds_bytes);
 int hop_workgroups_per_cu(int log2n, bool default_window);
 // Launchers. Return hipSuccess or the launch error. log2n in [5, 14].
 hipError_t launch_hop(int log2n, HopMode mode, const HopParams &p, hipStream_t s);
+// (between translation units) the N = 16384 fused path: rc_hop16k.hip, and rc_hop16k_prev.hip in the test-hook library
+hipError_t launch_hop16k(const HopParams &p, hipStream_t s);
+hipError_t launch_hop16k_prev(const HopParams &p, hipStream_t s);
 // tail_only: just save y_{last}[H..] of the chunk as the carried tail (no output written)
 hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only = false);
 // stage 0 = A (forward quarter FFTs), 1 = B (radix-4 + middle + radix-4), 2 = C (inverse quarter FFTs)

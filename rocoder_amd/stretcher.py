@@ -11,6 +11,7 @@ All numerics run in the HIP engine (librocoder_hip.so); nothing here computes au
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import queue
 import threading
 from dataclasses import dataclass
@@ -127,13 +128,14 @@ class Engine:
     """Thin RAII wrapper of rc_engine (all channels of one job)."""
 
     def __init__(self, **kw):
-        self._L = _lib.lib()
+        self._L = _lib.lib()  # (the test-hook build inside `_lib.hooks_library()`)
+        self._check = functools.partial(check, L=self._L)
         self._cfg, self._keep = make_config(**kw)
         h = C.c_void_p()
-        check(self._L.rc_engine_create(C.byref(self._cfg), C.byref(h)))
+        self._check(self._L.rc_engine_create(C.byref(self._cfg), C.byref(h)))
         self._h = h
         self.params = rc_params()
-        check(self._L.rc_engine_get_params(self._h, C.byref(self.params)))
+        self._check(self._L.rc_engine_get_params(self._h, C.byref(self.params)))
         self.channels = int(self._cfg.channels)
         self.window_len = int(self._cfg.window_len)
 
@@ -154,22 +156,22 @@ class Engine:
     # ---- streaming seam
     def push_input(self, channel: int, samples):
         s = np.ascontiguousarray(samples, dtype=np.float32)
-        check(self._L.rc_engine_push_input(self._h, channel, _fp(s), s.size))
+        self._check(self._L.rc_engine_push_input(self._h, channel, _fp(s), s.size))
 
     def close_input(self, channel: int):
-        check(self._L.rc_engine_close_input(self._h, channel))
+        self._check(self._L.rc_engine_close_input(self._h, channel))
 
     def next_window(self, channel: int) -> Optional[np.ndarray]:
         """One Stretcher::next_window; None when the reference would block on recv()."""
         out = np.empty(self.params.window_out_len, np.float32)
         n = C.c_size_t(0)
-        rc = check(self._L.rc_engine_next_window(self._h, channel, _fp(out), out.size, C.byref(n)))
+        rc = self._check(self._L.rc_engine_next_window(self._h, channel, _fp(out), out.size, C.byref(n)))
         if rc == RC_WOULD_BLOCK:
             return None
         return out[: n.value]
 
     def is_done(self, channel: int) -> bool:
-        return bool(check(self._L.rc_engine_is_done(self._h, channel)))
+        return bool(self._check(self._L.rc_engine_is_done(self._h, channel)))
 
     def channel_bound(self) -> int:
         return int(self._L.rc_engine_channel_bound(self._h))
@@ -188,14 +190,14 @@ class Engine:
         ins = (fp * self.channels)(*[_fp(x[c]) for c in range(self.channels)])
         outs = (fp * self.channels)(*[_fp(out[c]) for c in range(self.channels)])
         got = C.c_size_t(0)
-        check(self._L.rc_engine_stretch_host(self._h, ins, x.shape[1], outs, n_out, C.byref(got)))
+        self._check(self._L.rc_engine_stretch_host(self._h, ins, x.shape[1], outs, n_out, C.byref(got)))
         assert got.value == n_out
         return out
 
     def stretch_device_ptr(self, d_in: int, in_stride: int, in_len: int, d_out: int, out_stride: int,
                            out_cap: int, stream: int = 0) -> int:
         got = C.c_size_t(0)
-        check(self._L.rc_engine_stretch_device(self._h, C.c_void_p(d_in), in_stride, in_len,
+        self._check(self._L.rc_engine_stretch_device(self._h, C.c_void_p(d_in), in_stride, in_len,
                                                C.c_void_p(d_out), out_stride, out_cap, C.byref(got),
                                                C.c_void_p(stream)))
         return got.value
@@ -203,7 +205,7 @@ class Engine:
     def stretch_device_range_ptr(self, d_in: int, in_stride: int, in_len: int, ch_first: int,
                                  ch_count: int, win_first: int, win_count: int, d_out: int,
                                  out_stride: int, out_cap: int, stream: int = 0):
-        check(self._L.rc_engine_stretch_device_range(self._h, C.c_void_p(d_in), in_stride, in_len,
+        self._check(self._L.rc_engine_stretch_device_range(self._h, C.c_void_p(d_in), in_stride, in_len,
                                                      ch_first, ch_count, win_first, win_count,
                                                      C.c_void_p(d_out), out_stride, out_cap,
                                                      C.c_void_p(stream)))
@@ -228,11 +230,11 @@ class Engine:
         return out
 
     def synchronize(self):
-        check(self._L.rc_engine_synchronize(self._h))
+        self._check(self._L.rc_engine_synchronize(self._h))
 
     def last_kernel_stats(self):
         ms, hops, launches = C.c_float(0), C.c_uint64(0), C.c_uint32(0)
-        check(self._L.rc_engine_last_kernel_stats(self._h, C.byref(ms), C.byref(hops),
+        self._check(self._L.rc_engine_last_kernel_stats(self._h, C.byref(ms), C.byref(hops),
                                                   C.byref(launches)))
         return float(ms.value), int(hops.value), int(launches.value)
 
@@ -240,7 +242,7 @@ class Engine:
         """Event times (ms) of the kernel launches of the last min(n, 64) offline calls, oldest first."""
         buf = (C.c_float * n)()
         got = C.c_size_t(0)
-        check(self._L.rc_engine_kernel_times(self._h, buf, n, C.byref(got)))
+        self._check(self._L.rc_engine_kernel_times(self._h, buf, n, C.byref(got)))
         return [float(buf[i]) for i in range(got.value)]
 
     # ---- single hop (ReFFT seam)
@@ -248,14 +250,14 @@ class Engine:
         s = np.ascontiguousarray(samples, dtype=np.float32)
         assert s.size == self.window_len
         out = np.empty(2 * self.window_len, np.float32)
-        check(self._L.rc_engine_forward_fft(self._h, _fp(s), _fp(out)))
+        self._check(self._L.rc_engine_forward_fft(self._h, _fp(s), _fp(out)))
         return out.view(np.complex64)
 
     def resynth(self, channel: int, hop: int, samples) -> np.ndarray:
         s = np.ascontiguousarray(samples, dtype=np.float32)
         assert s.size == self.window_len
         out = np.empty(self.window_len, np.float32)
-        check(self._L.rc_engine_resynth(self._h, channel, hop, _fp(s), _fp(out)))
+        self._check(self._L.rc_engine_resynth(self._h, channel, hop, _fp(s), _fp(out)))
         return out
 
 

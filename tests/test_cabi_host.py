@@ -32,6 +32,24 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.rc_abi_version() == 2
 
 
+def test_product_library_reads_no_diagnostic_variable_and_hook_build_loads():
+    """ROCODER_DIAG and the run-planner tuning variables change what an engine computes with; only the test-hook
+    build (`make hooks`, -DRC_TEST_HOOKS=1) may read them - the product library must not even contain their names.
+    The hook build exports the same C-ABI."""
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"ROCODER_DIAG", b"ROCODER_ROUNDS", b"ROCODER_MIN_RUN", b"ROCODER_B4_ROUNDS"):
+        assert name not in blob, name
+    assert b"hop3_kernel" not in blob  # the previous kernel generation lives in the hook build only
+    hooks = open(_lib.HOOKS_PATH, "rb").read()
+    assert b"ROCODER_DIAG" in hooks and b"hop3_kernel" in hooks
+    with _lib.hooks_library() as H:
+        assert _lib.lib() is H
+        for n in _header_functions():
+            assert hasattr(H, n), n
+        assert H.rc_abi_version() == _lib.lib().rc_abi_version()
+    assert _lib.lib() is not H
+
+
 @pytest.mark.parametrize("N,f,p,a", [(16384, 1.0, 1, 1.0), (16384, 8.0, 1, 1.0), (16384, 8.0, 3, 1.0),
                                      (65536, 32.0, 1, 1.0), (1024, 2.0, 2, 0.7), (256, 0.5, 1, 1.0),
                                      (16384, 8.0, -2, 1.0), (16384, 40.0, 5, 2.0)])

@@ -377,8 +377,11 @@ def test_band_mask_fused_into_the_16384_kernel(monkeypatch, p):
         got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=23, device_kernel=("band", lo, hi, gi, go))
         ref = oc.stretch_offline(x, N, f, 1.0, p, seed=23, kernel=_np_band(lo, hi, gi, go))
         assert_parity(got, ref, f"band {lo}..{hi} gains {gi}/{go} p={p}")
+    from rocoder_amd import _lib
+
     monkeypatch.setenv("ROCODER_DIAG", "2")
-    old = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=23, device_kernel=("band", 900, 100, 5.0, 0.75))
+    with _lib.hooks_library():  # (only the test-hook build reads ROCODER_DIAG)
+        old = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=23, device_kernel=("band", 900, 100, 5.0, 0.75))
     assert_parity(got, old, "fused vs unfused band mask")
 
 
@@ -850,7 +853,7 @@ def test_hop4_agrees_with_previous_kernel_generation(monkeypatch, p):
     """hop4_kernel changes which thread holds which elements between passes (wave-local exchanges) and how
     thread 0's self-paired bins are computed (packed arithmetic in registers instead of the scalar LDS
     side path); everything else is hop3_kernel's operation for operation (the first hop4, which kept the
-    side path, was bit-identical). hop3 stays in the library behind ROCODER_DIAG=2 for this check and for
+    side path, was bit-identical). hop3 stays in the test-hook library (make hooks) behind ROCODER_DIAG=2 for this check and for
     A/B timing: the two must agree far inside the tolerance (hop4 also fuses the analysis window into the
     first butterfly stage and folds the amplitude into the envelope, so single roundings differ)."""
     import torch
@@ -861,8 +864,10 @@ def test_hop4_agrees_with_previous_kernel_generation(monkeypatch, p):
     with ra.Engine(window_len=16384, factor=8.0, pitch_multiple=p, channels=2, seed=77) as e:
         new = e.stretch_tensor(xt).clone()
         torch.cuda.synchronize()
+    from rocoder_amd import _lib
+
     monkeypatch.setenv("ROCODER_DIAG", "2")
-    with ra.Engine(window_len=16384, factor=8.0, pitch_multiple=p, channels=2, seed=77) as e:
+    with _lib.hooks_library(), ra.Engine(window_len=16384, factor=8.0, pitch_multiple=p, channels=2, seed=77) as e:
         old = e.stretch_tensor(xt).clone()
         torch.cuda.synchronize()
     assert torch.isfinite(new).all() and float(new.abs().max()) > 0.01
@@ -886,7 +891,7 @@ def test_baseline_c1_full_size_every_sample():
 def test_big4_agrees_with_three_kernel_pipeline_at_c5_size(monkeypatch):
     """BASELINE C5 at full size, every sample of all eight channels: the fused big4_kernel (one workgroup per
     run of hops, tail through its per-workgroup scratch) against the three-kernel pipeline through HBM scratch
-    that computed C5 in round 1 (kept behind ROCODER_DIAG=2). Different FFT factorisations, same bins, same
+    that computed C5 in round 1 (selected by ROCODER_DIAG=2 in the test-hook library). Different FFT factorisations, same bins, same
     phases: they must agree far inside the tolerance at every run / scratch position of the full-size job."""
     import torch
 
@@ -896,8 +901,10 @@ def test_big4_agrees_with_three_kernel_pipeline_at_c5_size(monkeypatch):
     with ra.Engine(window_len=N, factor=f, channels=C, seed=seed) as e:
         new = e.stretch_tensor(xt).clone()
         torch.cuda.synchronize()
+    from rocoder_amd import _lib
+
     monkeypatch.setenv("ROCODER_DIAG", "2")
-    with ra.Engine(window_len=N, factor=f, channels=C, seed=seed) as e:
+    with _lib.hooks_library(), ra.Engine(window_len=N, factor=f, channels=C, seed=seed) as e:
         old = e.stretch_tensor(xt).clone()
         torch.cuda.synchronize()
     assert new.shape == old.shape == (C, 167_313_408)
@@ -922,14 +929,14 @@ def test_seam_wait_expiry_fails_loudly(monkeypatch):
     x = np.stack([onp.synth_input(c, 1_200_000) for c in range(2)])
     xt = torch.from_numpy(x).cuda()
     monkeypatch.setenv("ROCODER_DIAG", "1")
-    with ra.Engine(window_len=16384, factor=8.0, channels=2, seed=3) as e:
+    with _lib.hooks_library(), ra.Engine(window_len=16384, factor=8.0, channels=2, seed=3) as e:
         with pytest.raises(_lib.RocoderError) as ei:
             e.stretch_tensor(xt)  # (asynchronous on a caller stream: the error then comes from the next call)
             torch.cuda.synchronize()
             e.synchronize()
         assert ei.value.code == _lib.RC_EHIP and "seam" in str(ei.value)
         e.synchronize()  # reported once
-    monkeypatch.delenv("ROCODER_DIAG")
+    # the product library ignores the variable altogether
     with ra.Engine(window_len=16384, factor=8.0, channels=2, seed=3) as e:
         out = e.stretch_tensor(xt)
         torch.cuda.synchronize()

@@ -1,12 +1,8 @@
 #!/bin/bash
-# tools/build_variant.sh NAME [extra hipcc flags...] -> rocoder_amd/lib_NAME.so (A/B timing builds)
+# tools/build_variant.sh NAME [extra hipcc flags...] -> rocoder_amd/lib_NAME.so (A/B timing / diagnostic builds;
+# load it with ROCODER_HIP_LIB=rocoder_amd/lib_NAME.so). Add -DRC_TEST_HOOKS=1 for a variant that reads ROCODER_DIAG
+# and the run-planner tuning variables (then also pass KERNELS through: see `make hooks`).
 set -e
 NAME=$1; shift
-cd "$(dirname "$0")/../rocoder_amd/csrc"
-B=/tmp/rcvar_$NAME; mkdir -p $B
-FLAGS="-DRC_PMAX=32 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 -ffp-contract=fast -fno-slp-vectorize $*"
-/opt/rocm/bin/hipcc $FLAGS -c rc_kernels.hip -o $B/k.o &
-/opt/rocm/bin/hipcc $FLAGS -x hip -c rc_engine.cpp -o $B/e.o &
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib_$NAME.so $B/k.o $B/e.o
-echo built ../lib_$NAME.so
+make -s -j6 -C "$(dirname "$0")/../rocoder_amd/csrc" variant NAME="$NAME" EXTRA="$*"
+echo built rocoder_amd/lib_$NAME.so

@@ -3,6 +3,7 @@
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_ab; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export ROCODER_HIP_LIB=$GRAFT_REPO_ROOT/rocoder_amd/librocoder_hip_hooks.so  # (the build that reads ROCODER_DIAG)
 for d in 0 2; do
  i=0
  for CNT in \

@@ -5,7 +5,7 @@ TAG=$1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $GRAFT_REPO_ROOT/tools/bench_c5.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err; cat $OUT/${TAG}_bench.json
-ROCODER_DIAG=2 python3 $GRAFT_REPO_ROOT/tools/bench_c5.py > $OUT/${TAG}_bench_prev_pipeline.json 2>> $OUT/bench.err
+ROCODER_HIP_LIB=$GRAFT_REPO_ROOT/rocoder_amd/librocoder_hip_hooks.so ROCODER_DIAG=2 python3 $GRAFT_REPO_ROOT/tools/bench_c5.py > $OUT/${TAG}_bench_prev_pipeline.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tools/bench_c5.py > $OUT/trace.log 2>&1
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
 head -6 $OUT/${TAG}_kernel_stats.csv | cut -c1-200

@@ -1,5 +1,6 @@
 #!/bin/bash
 # sweep the run planner of the N = 16384 kernel on one box: tools/sweep_rounds.sh "4 6 8 12" "4 8"
+export ROCODER_HIP_LIB=$PWD/rocoder_amd/librocoder_hip_hooks.so  # (the build that reads the tuning variables)
 for rep in 1 2; do
 for mr in $2; do
 for r in $1; do
