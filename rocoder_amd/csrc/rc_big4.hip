@@ -49,8 +49,13 @@ __device__ constexpr HannK64 HANN_E15 = make_hann_k64(HANN_ENV_AMP, 16384, 16);
 __device__ constexpr HannK64 HANN_W16 = make_hann_k64(0.5, 65536, 64);
 __device__ constexpr HannK64 HANN_E16 = make_hann_k64(HANN_ENV_AMP, 32768, 32);
 
+#ifndef RC_B4_STAGESB
+#define RC_B4_STAGESB 1
+#endif
 // dit_stages for up to 64 registers: 64th-root constants, otherwise the same arithmetic
-template <int NREG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L>
+// LEAN: one live twiddle at a time (for the R = 64 kernel with its carried tail in registers: 192 of the 256
+// registers are data)
+template <int NREG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L, bool LEAN = false>
 __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f}) {
     const v2f sgn = CONJ ? v2f{1.0f, -1.0f} : v2f{-1.0f, 1.0f};
     v2f bases[S_HI - S_LO + 1];
@@ -88,32 +93,58 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
             const v2f base = bases[s - S_LO];
             constexpr int NCMAX = NREG / 4 > 0 ? NREG / 4 : 1;
             const int nc = half > 1 ? half / 2 : 1;
-            v2f tw[NCMAX];
-#pragma unroll
-            for (int c = 0; c < NCMAX; ++c) {
-                if (c >= nc) continue;
-                const int kidx = c * (32 >> rb);
-                const v2f kc = {W64.re[kidx & 31], W64.im[kidx & 31]};
-                tw[c] = c == 0 ? base : vcmul(base, kc);
-            }
-#pragma unroll
-            for (int q0 = 0; q0 < NREG; ++q0) {
-                if (q0 & half) continue;
-                const int q1 = q0 | half;
-                const int c = q0 & (half - 1);
-                const v2f a = v[q0], b = v[q1];
-                if (c < nc) vdit_m<CONJ>(a, b, tw[c], v[q0], v[q1]);
-                else vdit_rot_m<CONJ>(a, b, tw[c - nc], v[q0], v[q1]);
+            if constexpr (LEAN) {
+                // twiddle by twiddle: tw = base W_64^kidx serves the butterflies with c = cc (as it is) and c = cc + nc
+                // (rotated by -i), then dies - one live twiddle instead of NREG / 4
+    #pragma unroll
+                for (int cc = 0; cc < NCMAX; ++cc) {
+                    if (cc >= nc) continue;
+                    const int kidx = cc * (32 >> rb);
+                    const v2f kc = {W64.re[kidx & 31], W64.im[kidx & 31]};
+                    const v2f tw = cc == 0 ? base : vcmul(base, kc);
+    #pragma unroll
+                    for (int blk = 0; blk < NREG / 2; ++blk) {  // (blocks of 2 half registers; only NREG / (2 half) exist)
+                        if (blk * 2 * half >= NREG) continue;
+                        const int q0 = blk * 2 * half + cc, q1 = q0 | half;
+                        {
+                            const v2f a = v[q0], b = v[q1];
+                            vdit_m<CONJ>(a, b, tw, v[q0], v[q1]);
+                        }
+                        if (half > 1) {
+                            const v2f a = v[q0 + nc], b = v[q1 + nc];
+                            vdit_rot_m<CONJ>(a, b, tw, v[q0 + nc], v[q1 + nc]);
+                        }
+                    }
+                }
+                if (RC_B4_STAGESB) __builtin_amdgcn_sched_barrier(0);  // stages do not overlap (their temporaries would add up)
+            } else {
+                v2f tw[NCMAX];
+    #pragma unroll
+                for (int c = 0; c < NCMAX; ++c) {
+                    if (c >= nc) continue;
+                    const int kidx = c * (32 >> rb);
+                    const v2f kc = {W64.re[kidx & 31], W64.im[kidx & 31]};
+                    tw[c] = c == 0 ? base : vcmul(base, kc);
+                }
+    #pragma unroll
+                for (int q0 = 0; q0 < NREG; ++q0) {
+                    if (q0 & half) continue;
+                    const int q1 = q0 | half;
+                    const int c = q0 & (half - 1);
+                    const v2f a = v[q0], b = v[q1];
+                    if (c < nc) vdit_m<CONJ>(a, b, tw[c], v[q0], v[q1]);
+                    else vdit_rot_m<CONJ>(a, b, tw[c - nc], v[q0], v[q1]);
+                }
             }
         }
     }
 }
 
 #ifndef RC_B4_LB
-#define RC_B4_LB 32
+#define RC_B4_LB 16  // R = 64: input rows in flight per batch (8 pairs; 32 leave no room next to the register tail)
 #endif
 #ifndef RC_B4_TAILREG_MAX
-#define RC_B4_TAILREG_MAX 32  // largest R whose carried tail lives in registers (above: per-workgroup scratch)
+#define RC_B4_TAILREG_MAX 64  // largest R whose carried tail lives in registers (above: per-workgroup scratch)
 #endif
 #ifndef RC_B4_LGKM
 #define RC_B4_LGKM 1
@@ -145,6 +176,18 @@ __device__ __forceinline__ void tail_st(GV2W p, v2f v) {
 #ifndef RC_B4_TPRE
 #define RC_B4_TPRE 0
 #endif
+// R = 64: the last inverse stage (the one that pairs head sample q with tail sample q + PH) is computed inside
+// the epilogue, one register pair at a time with its twiddle rebuilt on the spot, instead of inside I3 with 16
+// twiddles (32 VGPRs) live next to the 128 data registers: that is what makes room for the carried tail
+#ifndef RC_B4_PAIRLOAD
+#define RC_B4_PAIRLOAD 1  // input rows fetched in butterfly-pair order, stage 0 inside the load loop
+#endif
+#ifndef RC_B4_LOCALID
+#define RC_B4_LOCALID 1  // R = 64: thread identities re-derived per phase from an opaque copy of the thread id
+#endif
+#ifndef RC_B4_FUSE_LAST
+#define RC_B4_FUSE_LAST 1
+#endif
 constexpr int BIG4_T = 512;
 constexpr int BIG4_XBUF = 16400;  // exchange buffer, float2 slots (16384 + the 15 of the E1 / E3 index map)
 // tables behind the buffer: W_M^r [TA], W_N^r [TR] for r <= RES/2, thread 0's second twiddle base
@@ -156,6 +199,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
     constexpr int RES = 1 << (b + 5), G = R / 32, NS = R / 16, PH = R / 2;
     constexpr int T_A = BIG4_XBUF, T_R = T_A + RES / 2 + 1, SCR = T_R + RES / 2 + 1;
     constexpr bool TAIL_GLOBAL = R > RC_B4_TAILREG_MAX;
+    constexpr bool LEAN = !TAIL_GLOBAL && R > 32;  // 192 data registers: everything else is kept short-lived
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const uint32_t run = blockIdx.x % p.runs_per_channel;
@@ -198,12 +242,16 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
         for (int q = 0; q < PH; ++q) stg2(tsc + T * q + (unsigned)tid, make_float2(0.f, 0.f));
     }
-    // thread identities
-    const int lf = tid & 31, uu = tid >> 5;   // F2
-    const int l4 = tid & 15, hi = tid >> 4;   // I2
     const bool is0 = tid == 0;
     Stamps stp;
     stp.init();
+    // Thread identities are re-derived from an opaque copy of the thread id inside each phase: left to itself the
+    // compiler hoists the ~40 loop-invariant LDS bases / residues out of the hop loop and then spills them
+    auto ptid = [&]() {
+        int t = tid;
+        if (RC_B4_LOCALID && R > 32) opaque(t);  // (R = 32 has the registers: there the hoisted values are 2 % faster)
+        return t;
+    };
     // RC_B4_DMA (R = 32): the next hop's whole window (N floats = the exchange buffer's size) is fetched by LDS-DMA
     // (global_load_lds_dwordx4: no VGPRs) into the exchange buffer while it is idle - from the last E4 read to the
     // next E1 write - so that its latency runs under I3 and the epilogue instead of in front of F1
@@ -219,7 +267,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             GF win = per_hop(p.window);
             v2f cbW = {0.f, 0.f}, sbW = cbW;
             if constexpr (HANN) {  // {cos, sin}(beta) of this thread's two samples, from the engine's table
-                GV2 hr = (GV2)per_hop(p.hann_rot) + 2 * tid;
+                GV2 hr = (GV2)per_hop(p.hann_rot) + 2 * tt;
                 const float2 a0 = ldg2(hr), a1 = ldg2(hr + 1);
                 cbW = v2f{a0.x, a1.x};
                 sbW = v2f{a0.y, a1.y};
@@ -234,47 +282,67 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 if (PITCH1 && k - 1 >= k_begin) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             }
+            // rows are fetched in the order 0, R/2, 1, R/2 + 1, ...: butterfly stage 0 pairs row q with row q + R/2 (registers
+            // brev(q) and brev(q) + 1), and the compiler folds the second row's window multiply into that butterfly, so a
+            // row loaded long before its partner would wait for it as two live values (raw samples and window)
+#define ROW(i) (RC_B4_PAIRLOAD ? (((i) >> 1) + ((i) & 1) * (R / 2)) : (i))
 #pragma unroll
             for (int q0 = 0; q0 < R; q0 += LB) {
                 float xr0[LB], xr1[LB], wr0[HANN ? 1 : LB], wr1[HANN ? 1 : LB];
 #pragma unroll
                 for (int q = 0; q < LB; ++q) {
                     if (DMA && dma_ready) {  // (uniform) z[n], n = tid + 512 q, sits at float2 slot n
-                        const float2 zz = lds[tid + T * (q0 + q)];
+                        const float2 zz = lds[tid + T * ROW(q0 + q)];
                         xr0[q] = zz.x;
                         xr1[q] = zz.y;
                     } else
                     if (RC_B4_ABL & 1) {  // timing only: no input loads
-                        xr0[q] = (float)(lane2 + q0 + q) + (float)k;
+                        xr0[q] = (float)(lane2 + ROW(q0 + q)) + (float)k;
                         xr1[q] = xr0[q] * 0.5f;
                     } else {
-                        xr0[q] = (src + 2 * T * (q0 + q))[lane2];
-                        xr1[q] = (src + 2 * T * (q0 + q))[lane2 + 1];
+                        xr0[q] = (src + 2 * T * ROW(q0 + q))[lane2];
+                        xr1[q] = (src + 2 * T * ROW(q0 + q))[lane2 + 1];
                     }
                     if constexpr (!HANN) {
-                        wr0[q] = (win + 2 * T * (q0 + q))[lane2];
-                        wr1[q] = (win + 2 * T * (q0 + q))[lane2 + 1];
+                        wr0[q] = (win + 2 * T * ROW(q0 + q))[lane2];
+                        wr1[q] = (win + 2 * T * ROW(q0 + q))[lane2 + 1];
                     }
                 }
+                v2f wq[LB];
 #pragma unroll
                 for (int q = 0; q < LB; ++q) {
-                    v2f wq;
                     if constexpr (HANN)
-                        wq = __builtin_elementwise_fma(v2f{HW.s[q0 + q], HW.s[q0 + q]}, sbW,
-                             __builtin_elementwise_fma(v2f{HW.c[q0 + q], HW.c[q0 + q]}, cbW, v2f{0.5f, 0.5f}));
+                        wq[q] = __builtin_elementwise_fma(v2f{HW.s[ROW(q0 + q)], HW.s[ROW(q0 + q)]}, sbW,
+                                __builtin_elementwise_fma(v2f{HW.c[ROW(q0 + q)], HW.c[ROW(q0 + q)]}, cbW, v2f{0.5f, 0.5f}));
                     else
-                        wq = v2f{wr0[q], wr1[q]};
-                    v[brev_c(q0 + q, b)] = v2f{xr0[q], xr1[q]} * wq;
+                        wq[q] = v2f{wr0[q], wr1[q]};
                 }
+                // butterfly stage 0 right here (registers brev(q) and brev(q) + 1 = rows q and q + R/2): a +- b with
+                // a = x_q w_q and b = x_{q+R/2} w_{q+R/2} is one multiply and two FMAs
+                if constexpr (RC_B4_PAIRLOAD) {
+#pragma unroll
+                    for (int q = 0; q < LB; q += 2) {
+                        const v2f a = v2f{xr0[q], xr1[q]} * wq[q], xh = v2f{xr0[q + 1], xr1[q + 1]};
+                        v[brev_c(ROW(q0 + q), b)] = __builtin_elementwise_fma(xh, wq[q + 1], a);
+                        v[brev_c(ROW(q0 + q), b) + 1] = __builtin_elementwise_fma(-xh, wq[q + 1], a);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < LB; ++q) v[brev_c(q0 + q, b)] = v2f{xr0[q], xr1[q]} * wq[q];
+                }
+                // the register tail leaves no room for a second batch in flight: keep the batches apart
+                if constexpr (!TAIL_GLOBAL && R > 32) __builtin_amdgcn_sched_barrier(0);
             }
+#undef ROW
             stp.mark(0);
-            dit_g<R, 0, b - 1, 0, false, false>(v);
+            dit_g<R, RC_B4_PAIRLOAD ? 1 : 0, b - 1, 0, false, false>(v);
         }
         stp.mark(1);
         // ---- E1: F1 -> F2, round g moves the registers with position bit 5 = g
         v2f w[R];
         {
-            const int bs = (int)(__brev((unsigned)tid) >> 23);           // brev9(t)
+            const int t_ = ptid(), lf = t_ & 31, uu = t_ >> 5;
+            const int bs = (int)(__brev((unsigned)t_) >> 23);            // brev9(t)
             const int b1s = (bs << 5) + (bs >> 5);                       // e1(q | brev9(t) << 5) = q + this
             const int b1l = lf + (uu << 10) + uu;                        // e1(lf | j << 5 | uu << 10) = (j << 5) + this
 #pragma unroll
@@ -289,13 +357,14 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         }
         stp.mark(2);
         {   // F2: stages b..b+4 on each group; base W_RES^(lf | g << 5) = W_M^(16 lf) * (g ? W_64 : 1)
+            const int lf = ptid() & 31;
             const v2f wf0 = to_v(lds[T_A + 16 * lf]);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 v2f grp[32];
 #pragma unroll
                 for (int j = 0; j < 32; ++j) grp[j] = w[32 * g + j];
-                dit_g<32, b, b + 4, b, false, true>(grp, g ? vcmul(wf0, v2f{W64.re[1], W64.im[1]}) : wf0);
+                dit_g<32, b, b + 4, b, false, true, LEAN>(grp, g ? vcmul(wf0, v2f{W64.re[1], W64.im[1]}) : wf0);
 #pragma unroll
                 for (int j = 0; j < 32; ++j) w[32 * g + j] = grp[j];
             }
@@ -304,6 +373,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         // ---- E2: F2 -> F3. slot = (residue mod 1024) | uu << 10; R = 64: round 0 = residues < 1024
         v2f st[NS][16];
         {
+            const int tid = ptid(), lf = tid & 31, uu = tid >> 5;
             const int b2s = lf | (uu << 10);
 #pragma unroll
             for (int rnd = 0; rnd < G; ++rnd) {
@@ -328,7 +398,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         // ---- F3 on every set, middle stage on every (A, B) pair of sets, I1
 #pragma unroll
         for (int gp = 0; gp < NS / 2; ++gp) {
-            const int r = tid + 512 * gp;
+            const int r = ptid() + 512 * gp;
             v2f(&va)[16] = st[2 * gp];
             v2f(&vb)[16] = st[2 * gp + 1];
             {
@@ -336,8 +406,8 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 const v2f k16 = {W32_RE[2], W32_IM[2]};
                 v2f wb = vcmul(v2f{wa.x, -wa.y}, k16);  // W_M^(RES - r) = W_16 conj(W_M^r)
                 if (gp == 0 && is0) wb = v2f{W32_RE[1], W32_IM[1]};  // thread 0: residue RES/2 -> W_32
-                dit_g<16, b + 5, b + 8, b + 5, false, true>(va, wa);
-                dit_g<16, b + 5, b + 8, b + 5, false, true>(vb, wb);
+                dit_g<16, b + 5, b + 8, b + 5, false, true, LEAN>(va, wa);
+                dit_g<16, b + 5, b + 8, b + 5, false, true, LEAN>(vb, wb);
             }
             // thread 0, group 0: residues 0 and RES/2 pair with themselves (hop4_kernel's re-deal)
             const bool sp = gp == 0 && is0;
@@ -409,6 +479,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         stp.mark(5);
         // ---- E3: I1 -> I2. element P = q' | brev_{b+5}(residue) << 4; R = 64: P4 (= residue >= 1024) is the round
         {
+            const int tid = ptid(), l4 = tid & 15, hi = tid >> 4;
 #pragma unroll
             for (int rnd = 0; rnd < G; ++rnd) {
                 BIG4_BAR();
@@ -438,13 +509,14 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         }
         stp.mark(6);
         {   // I2: inverse stages 4..8 on each group, base W_512^l4 = W_M^(l4 R)
+            const int l4 = ptid() & 15;
             const v2f wf = to_v(lds[T_A + l4 * R]);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 v2f grp[32];
 #pragma unroll
                 for (int j = 0; j < 32; ++j) grp[j] = v[32 * g + j];
-                dit_g<32, 4, 8, 4, true, true>(grp, wf);
+                dit_g<32, 4, 8, 4, true, true, LEAN>(grp, wf);
 #pragma unroll
                 for (int j = 0; j < 32; ++j) v[32 * g + j] = grp[j];
             }
@@ -453,6 +525,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         // ---- E4: I2 -> I3 (registers = P9.., thread = P0..P8), round g = P14
         v2f y[R];
         {
+            const int tid = ptid(), l4 = tid & 15, hi = tid >> 4;
             const int b4s = l4 | (hi << 9);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
@@ -489,7 +562,22 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
             for (int q = 0; q < PH; ++q) tpre[q] = tail_ld((GV2)tsc + T * q + (unsigned)tt);
         }
-        dit_g<R, 9, m - 1, 9, true, true>(y, to_v(lds[T_A + tid]));
+        constexpr bool FUSE = R == 64 && RC_B4_FUSE_LAST;
+        if constexpr (FUSE) {  // stages 9..m-2 on each half (the two halves share their twiddles)
+            const v2f wfl = to_v(lds[T_A + ptid()]);
+            const v2f wf2 = vcmul(wfl, wfl);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                v2f grp[R / 2];
+#pragma unroll
+                for (int j = 0; j < R / 2; ++j) grp[j] = y[(R / 2) * g + j];
+                dit_g<R / 2, 9, m - 2, 9, true, true, LEAN>(grp, wf2);
+#pragma unroll
+                for (int j = 0; j < R / 2; ++j) y[(R / 2) * g + j] = grp[j];
+            }
+        } else {
+            dit_g<R, 9, m - 1, 9, true, true>(y, to_v(lds[T_A + ptid()]));
+        }
         stp.mark(9);
         // ---- epilogue: synthesis window, overlap-add, store (tail in registers or in the scratch)
         {
@@ -497,7 +585,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             GF esrc = per_hop(p.env);
             v2f cbW = {0.f, 0.f}, sbW = cbW, cbE = cbW, sbE = cbW;
             if constexpr (HANN) {
-                GV2 hr = (GV2)per_hop(p.hann_rot) + 2 * tid;
+                GV2 hr = (GV2)per_hop(p.hann_rot) + 2 * tt;
                 const float2 a0 = ldg2(hr), a1 = ldg2(hr + 1), e0r = ldg2(hr + 2 * T), e1r = ldg2(hr + 2 * T + 1);
                 cbW = v2f{a0.x, a1.x};
                 sbW = v2f{a0.y, a1.y};
@@ -558,8 +646,18 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 }
 #pragma unroll
                 for (int q = 0; q < EB; ++q) {
-                    const v2f head = y[q0 + q] * v2f{wr0[q], wr1[q]};
-                    const v2f nt = y[q0 + q + PH] * v2f{wt0[q], wt1[q]};
+                    v2f yh = y[q0 + q], yt = y[q0 + q + PH];
+                    if constexpr (FUSE) {  // inverse stage m-1: (yh, yt) = (a + conj(w) b, a - conj(w) b), w = W_M^tid W_64^c
+                        const int c = q0 + q;  // < 32
+                        const v2f wfl = to_v(lds[T_A + tt]);
+                        const v2f k64 = {W64.re[c & 15], W64.im[c & 15]};
+                        const v2f tw = (c & 15) == 0 ? wfl : vcmul(wfl, k64);
+                        const v2f a = yh, bb = yt;
+                        if (c < 16) vdit_m<true>(a, bb, tw, yh, yt);
+                        else vdit_rot_m<true>(a, bb, tw, yh, yt);
+                    }
+                    const v2f head = yh * v2f{wr0[q], wr1[q]};
+                    const v2f nt = yt * v2f{wt0[q], wt1[q]};
                     if (k >= k_begin) {
                         // stretcher.rs:97-100 operation order
                         const v2f o = (head + tq[q]) * v2f{e0[q], e1[q]} * ampk;
@@ -579,6 +677,8 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                     }
                     else tail[q0 + q] = nt;
                 }
+                // (register tail at R = 64: 192 registers are taken; keep the batches' window / twiddle temporaries apart)
+                if constexpr (!TAIL_GLOBAL && R > 32) __builtin_amdgcn_sched_barrier(0);
             }
         }
         stp.mark(10);
@@ -605,6 +705,10 @@ hipError_t launch_big4_r(const HopParams &p, hipStream_t s) {
 
 }  // namespace
 
+size_t big4_tail_scratch_floats(int log2n) {
+    const int R = log2n == 16 ? 64 : 32;
+    return R > RC_B4_TAILREG_MAX ? ((size_t)1 << log2n) / 2 : 0;
+}
 hipError_t launch_big4(int log2n, const HopParams &p, hipStream_t s) {
     if (log2n == 15) return launch_big4_r<32>(p, s);
     if (log2n == 16) return launch_big4_r<64>(p, s);

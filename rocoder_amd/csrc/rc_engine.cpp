@@ -691,8 +691,8 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         const uint64_t len = ((uint64_t)hop_count + r - 1) / r;
         p.run_len = (uint32_t)len;
         p.runs_per_channel = (uint32_t)(((uint64_t)hop_count + len - 1) / len);
-        if (e->log2n == 16) {  // the carried tail goes through a per-workgroup scratch (rc_big4.hip)
-            if (int rcs = e->d_ybuf.reserve((size_t)p.runs_per_channel * n_channels * H * sizeof(float))) return rcs;
+        if (const size_t tsf = rc::big4_tail_scratch_floats(e->log2n)) {  // (builds with the tail outside the registers)
+            if (int rcs = e->d_ybuf.reserve((size_t)p.runs_per_channel * n_channels * tsf * sizeof(float))) return rcs;
             p.ybuf = (float *)e->d_ybuf.p;
         }
 #ifdef RC_STAMP_DUMP

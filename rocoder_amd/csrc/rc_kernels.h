@@ -163,9 +163,13 @@ hipError_t launch_big(int stage, const BigParams &p, hipStream_t s, HopMode mode
 hipError_t launch_big_cr(const BigOlaParams &p, hipStream_t s);
 // Fused large-window kernel (log2n 15 / 16, pitch >= 1, no spectrum kernel): HopParams with
 // wtab = exp(-2 pi i k / M) [>= RES/2 + 1], rtab = exp(-2 pi i j / N) [>= RES/2 + 1], RES = N / 32, and for
-// log2n 16 ybuf = tail scratch of runs * n_channels * N/2 floats. One workgroup walks one run and
+// builds whose carried tail does not fit the registers (big4_tail_scratch_floats) ybuf = tail scratch of
+// runs * n_channels * N/2 floats. One workgroup walks one run and
 // recomputes the hop before it for its tail.
 hipError_t launch_big4(int log2n, const HopParams &p, hipStream_t s);
+// floats of per-workgroup tail scratch (HopParams::ybuf) big4_kernel needs per run for this window length: 0 when
+// the carried tail y_{k-1}[H..] lives in registers (the default build, both lengths)
+size_t big4_tail_scratch_floats(int log2n);
 
 // Curated on-GPU frequency kernels (rc_config::device_kernel, RC_DK_BAND / RC_DK_SHIFT): Y = K(X) on the
 // natural-order N-bin spectra [hops_total][N] between the forward and the resynthesis kernels.
