@@ -50,9 +50,43 @@ __device__ constexpr HannK64 HANN_W16 = make_hann_k64(0.5, 65536, 64);
 __device__ constexpr HannK64 HANN_E16 = make_hann_k64(HANN_ENV_AMP, 32768, 32);
 
 #ifndef RC_B4_STAGESB
-#define RC_B4_STAGESB 1
+#define RC_B4_STAGESB 0
 #endif
 // dit_stages for up to 64 registers: 64th-root constants, otherwise the same arithmetic
+// One DIT stage with a runtime base twiddle, twiddle by twiddle: tw = base W_64^kidx serves the butterflies with
+// c = cc (as it is) and c = cc + nc (rotated by -i), then dies - one live twiddle instead of NREG / 4. Every loop
+// bound is a compile-time constant of the template (the array indices must fold, or v[] ends up in scratch memory).
+template <int NREG, int RB, bool CONJ>
+__device__ __forceinline__ void lean_stage(v2f (&v)[NREG], v2f base) {
+    constexpr int half = 1 << RB, nc = half > 1 ? half / 2 : 1, nblk = NREG / (2 * half);
+#pragma unroll
+    for (int cc = 0; cc < nc; ++cc) {
+        const int kidx = cc * (32 >> RB);
+        const v2f kc = {W64.re[kidx & 31], W64.im[kidx & 31]};
+        const v2f tw = cc == 0 ? base : vcmul(base, kc);
+#pragma unroll
+        for (int blk = 0; blk < nblk; ++blk) {
+            const int q0 = blk * 2 * half + cc, q1 = q0 + half;
+            {
+                const v2f a = v[q0], b = v[q1];
+                vdit_m<CONJ>(a, b, tw, v[q0], v[q1]);
+            }
+            if constexpr (half > 1) {
+                const v2f a = v[q0 + nc], b = v[q1 + nc];
+                vdit_rot_m<CONJ>(a, b, tw, v[q0 + nc], v[q1 + nc]);
+            }
+        }
+    }
+}
+template <int NREG, int S_LO, int S_HI, int REG_LO, bool CONJ, int S = S_LO>
+__device__ __forceinline__ void lean_stages(v2f (&v)[NREG], const v2f (&bases)[S_HI - S_LO + 1]) {
+    if constexpr (S <= S_HI) {
+        lean_stage<NREG, S - REG_LO, CONJ>(v, bases[S - S_LO]);
+        if (RC_B4_STAGESB) __builtin_amdgcn_sched_barrier(0);  // stages do not overlap (their temporaries would add up)
+        lean_stages<NREG, S_LO, S_HI, REG_LO, CONJ, S + 1>(v, bases);
+    }
+}
+
 // LEAN: one live twiddle at a time (for the R = 64 kernel with its carried tail in registers: 192 of the 256
 // registers are data)
 template <int NREG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L, bool LEAN = false>
@@ -62,7 +96,11 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
     if (HAS_L) {
         bases[S_HI - S_LO] = wfine;
 #pragma unroll
-        for (int s = S_HI - 1; s >= S_LO; --s) bases[s - S_LO] = vcmul(bases[s + 1 - S_LO], bases[s + 1 - S_LO]);
+        for (int s = S_HI - 1; s >= S_LO; --s) bases[s - S_LO] = vcsq(bases[s + 1 - S_LO]);
+        if constexpr (LEAN) {
+            lean_stages<NREG, S_LO, S_HI, REG_LO, CONJ>(v, bases);
+            return;
+        }
     }
 #pragma unroll
     for (int s = S_LO; s <= S_HI; ++s) {
@@ -93,31 +131,7 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
             const v2f base = bases[s - S_LO];
             constexpr int NCMAX = NREG / 4 > 0 ? NREG / 4 : 1;
             const int nc = half > 1 ? half / 2 : 1;
-            if constexpr (LEAN) {
-                // twiddle by twiddle: tw = base W_64^kidx serves the butterflies with c = cc (as it is) and c = cc + nc
-                // (rotated by -i), then dies - one live twiddle instead of NREG / 4
-    #pragma unroll
-                for (int cc = 0; cc < NCMAX; ++cc) {
-                    if (cc >= nc) continue;
-                    const int kidx = cc * (32 >> rb);
-                    const v2f kc = {W64.re[kidx & 31], W64.im[kidx & 31]};
-                    const v2f tw = cc == 0 ? base : vcmul(base, kc);
-    #pragma unroll
-                    for (int blk = 0; blk < NREG / 2; ++blk) {  // (blocks of 2 half registers; only NREG / (2 half) exist)
-                        if (blk * 2 * half >= NREG) continue;
-                        const int q0 = blk * 2 * half + cc, q1 = q0 | half;
-                        {
-                            const v2f a = v[q0], b = v[q1];
-                            vdit_m<CONJ>(a, b, tw, v[q0], v[q1]);
-                        }
-                        if (half > 1) {
-                            const v2f a = v[q0 + nc], b = v[q1 + nc];
-                            vdit_rot_m<CONJ>(a, b, tw, v[q0 + nc], v[q1 + nc]);
-                        }
-                    }
-                }
-                if (RC_B4_STAGESB) __builtin_amdgcn_sched_barrier(0);  // stages do not overlap (their temporaries would add up)
-            } else {
+            {
                 v2f tw[NCMAX];
     #pragma unroll
                 for (int c = 0; c < NCMAX; ++c) {
@@ -179,6 +193,15 @@ __device__ __forceinline__ void tail_st(GV2W p, v2f v) {
 // R = 64: the last inverse stage (the one that pairs head sample q with tail sample q + PH) is computed inside
 // the epilogue, one register pair at a time with its twiddle rebuilt on the spot, instead of inside I3 with 16
 // twiddles (32 VGPRs) live next to the 128 data registers: that is what makes room for the carried tail
+#ifndef RC_B4_OVL
+#define RC_B4_OVL 5  // R = 64. bit 0: E1's second round of stores interleaved with F2 on the first group; bit 1: E2's
+                     // second round with F3 on the first round's sets; bit 2: E4's first round with I2 on the second
+                     // group and its second round with I3 on the first half; bit 3: E3's first round with I1 on the
+                     // second round's sets
+#endif
+#ifndef RC_B4_OVL_K
+#define RC_B4_OVL_K 4  // VALU instructions between two of the interleaved LDS stores (3 / 4 / 5 / 6 / 8 measured: flat, 4 best)
+#endif
 #ifndef RC_B4_PAIRLOAD
 #define RC_B4_PAIRLOAD 1  // input rows fetched in butterfly-pair order, stage 0 inside the load loop
 #endif
@@ -191,14 +214,34 @@ __device__ __forceinline__ void tail_st(GV2W p, v2f v) {
 constexpr int BIG4_T = 512;
 constexpr int BIG4_XBUF = 16400;  // exchange buffer, float2 slots (16384 + the 15 of the E1 / E3 index map)
 // tables behind the buffer: W_M^r [TA], W_N^r [TR] for r <= RES/2, thread 0's second twiddle base
-constexpr int big4_lds_float2(int R) { return BIG4_XBUF + 2 * (16 * R + 1) + 8; }
+// R = 64 with the carried tail in registers: the last RC_B4_TAIL_LDS of a thread's 32 tail pairs live in LDS instead
+// (behind the tables; 512 float2 per pair: what is left of the 160 KiB takes three) - 192 data registers plus the
+// temporaries of the widest phases are ~8 more than the allocator places, and what it spills instead goes through
+// scratch memory, in line behind the output stores (8 spilled dwords cost 2.3 %)
+#ifndef RC_B4_TAIL_LDS
+#define RC_B4_TAIL_LDS 5
+#endif
+constexpr int big4_tail_lds(int R) { return (R == 64 && R <= RC_B4_TAILREG_MAX) ? RC_B4_TAIL_LDS : 0; }
+// ... and to make room for them the W_N^r table (two reads per thread and hop, in the pair stage) stays in global
+// memory for that kernel: its loads are issued in front of the E2 exchange, far from any store
+constexpr bool big4_tr_global(int R) { return big4_tail_lds(R) > 3; }
+constexpr int big4_lds_float2(int R) {
+    return BIG4_XBUF + (big4_tr_global(R) ? 1 : 2) * (16 * R + 1) + 8 + 512 * big4_tail_lds(R);
+}
+static_assert(sizeof(float2) * big4_lds_float2(64) <= 160 * 1024, "big4 LDS budget");
 
 template <int R, bool PITCH1, bool HANN>
 __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
     constexpr int b = clog2(R), m = b + 9, LOG2N = m + 1, M = 1 << m, H = M, T = BIG4_T;
     constexpr int RES = 1 << (b + 5), G = R / 32, NS = R / 16, PH = R / 2;
-    constexpr int T_A = BIG4_XBUF, T_R = T_A + RES / 2 + 1, SCR = T_R + RES / 2 + 1;
+    constexpr bool TRG = big4_tr_global(R);
+    constexpr int T_A = BIG4_XBUF, T_R = T_A + RES / 2 + 1, SCR = T_R + (TRG ? 0 : RES / 2 + 1);
+    constexpr int TL = big4_tail_lds(R), TLB = SCR + 8, PHR = R / 2 - TL;  // tail pairs [PHR, R/2) live at lds[TLB + ...]
     constexpr bool TAIL_GLOBAL = R > RC_B4_TAILREG_MAX;
+    constexpr bool OVL1 = (RC_B4_OVL & 1) && R == 64;
+    constexpr bool OVL2 = (RC_B4_OVL & 2) && R == 64 && R <= RC_B4_TAILREG_MAX;
+    constexpr bool OVL3 = (RC_B4_OVL & 8) && R == 64;
+    constexpr bool OVL4 = (RC_B4_OVL & 4) && R == 64 && RC_B4_FUSE_LAST && !RC_B4_DMA && R <= RC_B4_TAILREG_MAX;
     constexpr bool LEAN = !TAIL_GLOBAL && R > 32;  // 192 data registers: everything else is kept short-lived
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
@@ -226,7 +269,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         GV2 rt = (GV2)p.rtab;  // exp(-2 pi i j / N)
         for (int i = tid; i <= RES / 2; i += T) {
             lds[T_A + i] = ldg2(wt + i);
-            lds[T_R + i] = ldg2(rt + i);
+            if constexpr (!TRG) lds[T_R + i] = ldg2(rt + i);
         }
         if (tid == 0) {  // W_N^(RES/2 - M/2) = i W_N^(RES/2): thread 0's twiddle base for its second residue
             const float2 wq = ldg2(rt + RES / 2);
@@ -234,10 +277,12 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         }
         __syncthreads();
     }
-    v2f tail[TAIL_GLOBAL ? 1 : PH];
+    v2f tail[TAIL_GLOBAL ? 1 : PHR];
     if constexpr (!TAIL_GLOBAL) {
 #pragma unroll
-        for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
+        for (int q = 0; q < PHR; ++q) tail[q] = v2f{0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < TL; ++q) lds[TLB + 512 * q + tid] = make_float2(0.f, 0.f);  // (read back by this thread only)
     } else {
 #pragma unroll
         for (int q = 0; q < PH; ++q) stg2(tsc + T * q + (unsigned)tid, make_float2(0.f, 0.f));
@@ -345,6 +390,48 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             const int bs = (int)(__brev((unsigned)t_) >> 23);            // brev9(t)
             const int b1s = (bs << 5) + (bs >> 5);                       // e1(q | brev9(t) << 5) = q + this
             const int b1l = lf + (uu << 10) + uu;                        // e1(lf | j << 5 | uu << 10) = (j << 5) + this
+            if constexpr (OVL1) {
+                // R = 64, two rounds: the LDS takes the 32 stores of a wave at ~50 cycles apiece while all eight waves
+                // store (80 B/clk per CU), so the second round's stores are issued one at a time between the butterflies
+                // of F2 on the first round's group instead of in front of a barrier
+                BIG4_BAR();
+#pragma unroll
+                for (int q = 0; q < 32; ++q) lds[b1s + q] = to_f2(v[q]);
+                BIG4_BAR();
+#pragma unroll
+                for (int j = 0; j < 32; ++j) w[j] = to_v(lds[b1l + (j << 5)]);
+                const v2f wf0 = to_v(lds[T_A + 16 * lf]);
+                BIG4_BAR();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 32; ++q) lds[b1s + q] = to_f2(v[32 + q]);
+                {
+                    v2f grp[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) grp[j] = w[j];
+                    dit_g<32, b, b + 4, b, false, true, LEAN>(grp, wf0);
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) w[j] = grp[j];
+                }
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // one DS write
+                    __builtin_amdgcn_sched_group_barrier(0x2, RC_B4_OVL_K, 0);  // then K VALU
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                BIG4_BAR();
+#pragma unroll
+                for (int j = 0; j < 32; ++j) w[32 + j] = to_v(lds[b1l + (j << 5)]);
+                stp.mark(2);
+                {
+                    v2f grp[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) grp[j] = w[32 + j];
+                    dit_g<32, b, b + 4, b, false, true, LEAN>(grp, vcmul(wf0, v2f{W64.re[1], W64.im[1]}));
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) w[32 + j] = grp[j];
+                }
+            } else {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 BIG4_BAR();
@@ -354,7 +441,9 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
                 for (int j = 0; j < 32; ++j) w[32 * g + j] = to_v(lds[b1l + (j << 5)]);
             }
+            }
         }
+        if constexpr (!OVL1) {
         stp.mark(2);
         {   // F2: stages b..b+4 on each group; base W_RES^(lf | g << 5) = W_M^(16 lf) * (g ? W_64 : 1)
             const int lf = ptid() & 31;
@@ -369,19 +458,40 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 for (int j = 0; j < 32; ++j) w[32 * g + j] = grp[j];
             }
         }
+        }
         stp.mark(3);
         // ---- E2: F2 -> F3. slot = (residue mod 1024) | uu << 10; R = 64: round 0 = residues < 1024
         v2f st[NS][16];
+        float2 wrg[TRG ? NS / 2 : 1];  // W_N^r of this thread's residues, requested here for the pair stage
+        if constexpr (TRG) {
+            GV2 rt = (GV2)per_hop(reinterpret_cast<const float *>(p.rtab)) + ptid();
+#pragma unroll
+            for (int gp = 0; gp < NS / 2; ++gp) wrg[gp] = ldg2(rt + 512 * gp);
+        }
         {
             const int tid = ptid(), lf = tid & 31, uu = tid >> 5;
             const int b2s = lf | (uu << 10);
 #pragma unroll
             for (int rnd = 0; rnd < G; ++rnd) {
                 BIG4_BAR();
+                if (OVL2 && rnd == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kk = 0; kk < 32; ++kk) {
                     if (R == 32) lds[b2s + (kk << 5)] = to_f2(w[kk]);
                     else lds[b2s + ((kk >> 4) << 5) + ((kk & 15) << 6)] = to_f2(w[32 * (kk >> 4) + 16 * rnd + (kk & 15)]);
+                }
+                if constexpr (OVL2) {
+                    if (rnd == 1) {  // F3 on the sets round 0 delivered (residues tid and tid + 512) between round 1's stores
+#pragma unroll
+                        for (int gp = 0; gp < NS / 2; ++gp)
+                            dit_g<16, b + 5, b + 8, b + 5, false, true, LEAN>(st[2 * gp], to_v(lds[T_A + tid + 512 * gp]));
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, RC_B4_OVL_K, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 BIG4_BAR();
 #pragma unroll
@@ -406,7 +516,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 const v2f k16 = {W32_RE[2], W32_IM[2]};
                 v2f wb = vcmul(v2f{wa.x, -wa.y}, k16);  // W_M^(RES - r) = W_16 conj(W_M^r)
                 if (gp == 0 && is0) wb = v2f{W32_RE[1], W32_IM[1]};  // thread 0: residue RES/2 -> W_32
-                dit_g<16, b + 5, b + 8, b + 5, false, true, LEAN>(va, wa);
+                if constexpr (!OVL2) dit_g<16, b + 5, b + 8, b + 5, false, true, LEAN>(va, wa);
                 dit_g<16, b + 5, b + 8, b + 5, false, true, LEAN>(vb, wb);
             }
             // thread 0, group 0: residues 0 and RES/2 pair with themselves (hop4_kernel's re-deal)
@@ -424,8 +534,15 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 }
             }
             {
-                const float2 wrl = lds[T_R + r];
-                const float2 wrh = lds[sp ? SCR : T_R + r];
+                float2 wrl, wrh;
+                if constexpr (TRG) {
+                    wrl = wrg[gp];
+                    const float2 w0 = lds[SCR];
+                    wrh = make_float2(sp ? w0.x : wrl.x, sp ? w0.y : wrl.y);
+                } else {
+                    wrl = lds[T_R + r];
+                    wrh = lds[sp ? SCR : T_R + r];
+                }
                 const uint32_t x0 = (uint32_t)r * key.mul + key.k0;
                 const uint32_t dx = (uint32_t)RES * key.mul;
                 const uint32_t x0h = x0 - (sp ? (uint32_t)(M / 2 - RES / 2) * key.mul : 0u);
@@ -469,7 +586,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 pb[brev_c(q, 4)] = vb[q];
             }
             dit_g<16, 0, 3, 0, true, false>(pa);
-            dit_g<16, 0, 3, 0, true, false>(pb);
+            if constexpr (!OVL3) dit_g<16, 0, 3, 0, true, false>(pb);  // (OVL3: between the stores of E3's first round)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 va[q] = pa[q];
@@ -483,6 +600,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
             for (int rnd = 0; rnd < G; ++rnd) {
                 BIG4_BAR();
+                if (OVL3 && rnd == 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     if (R == 64 && ((s & 1) != rnd)) continue;
@@ -494,6 +612,18 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                     const int base = n0 + ((n0 >> 10) & 15);
 #pragma unroll
                     for (int q = 0; q < 16; ++q) lds[base + q] = to_f2(st[s][q]);
+                }
+                if constexpr (OVL3) {
+                    if (rnd == 0) {  // I1 on the sets of round 1 (the vb of both pairs; they hold brev4-ordered inputs)
+#pragma unroll
+                        for (int gp = 0; gp < NS / 2; ++gp) dit_g<16, 0, 3, 0, true, false>(st[2 * gp + 1]);
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x2, RC_B4_OVL_K, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
                 BIG4_BAR();
 #pragma unroll
@@ -508,6 +638,76 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             }
         }
         stp.mark(6);
+        constexpr bool FUSE = R == 64 && RC_B4_FUSE_LAST;
+        v2f y[R];
+        if constexpr (OVL4) {
+            // I2 on group 0; E4 round 0's stores between the butterflies of I2 on group 1; E4 round 1's stores between
+            // those of I3 (stages 9..m-2) on the half that round 0 delivered
+            const int tid = ptid(), l4 = tid & 15, hi = tid >> 4;
+            const int b4s = l4 | (hi << 9);
+            const v2f wf = to_v(lds[T_A + l4 * R]);
+            {
+                v2f grp[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) grp[j] = v[j];
+                dit_g<32, 4, 8, 4, true, true, LEAN>(grp, wf);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) v[j] = grp[j];
+            }
+            BIG4_BAR();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) lds[b4s + (j << 4)] = to_f2(v[j]);
+            {
+                v2f grp[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) grp[j] = v[32 + j];
+                dit_g<32, 4, 8, 4, true, true, LEAN>(grp, wf);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) v[32 + j] = grp[j];
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, RC_B4_OVL_K, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stp.mark(7);
+            BIG4_BAR();
+#pragma unroll
+            for (int q = 0; q < 32; ++q) y[q] = to_v(lds[tid + (q << 9)]);
+            const v2f wf2 = vcsq(to_v(lds[T_A + tid]));
+            BIG4_BAR();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) lds[b4s + (j << 4)] = to_f2(v[32 + j]);
+            {
+                v2f grp[R / 2];
+#pragma unroll
+                for (int j = 0; j < R / 2; ++j) grp[j] = y[j];
+                dit_g<R / 2, 9, m - 2, 9, true, true, LEAN>(grp, wf2);
+#pragma unroll
+                for (int j = 0; j < R / 2; ++j) y[j] = grp[j];
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, RC_B4_OVL_K, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            BIG4_BAR();
+#pragma unroll
+            for (int q = 0; q < 32; ++q) y[q + 32] = to_v(lds[tid + (q << 9)]);
+            stp.mark(8);
+            {
+                v2f grp[R / 2];
+#pragma unroll
+                for (int j = 0; j < R / 2; ++j) grp[j] = y[R / 2 + j];
+                dit_g<R / 2, 9, m - 2, 9, true, true, LEAN>(grp, wf2);
+#pragma unroll
+                for (int j = 0; j < R / 2; ++j) y[R / 2 + j] = grp[j];
+            }
+        } else {
         {   // I2: inverse stages 4..8 on each group, base W_512^l4 = W_M^(l4 R)
             const int l4 = ptid() & 15;
             const v2f wf = to_v(lds[T_A + l4 * R]);
@@ -523,7 +723,6 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         }
         stp.mark(7);
         // ---- E4: I2 -> I3 (registers = P9.., thread = P0..P8), round g = P14
-        v2f y[R];
         {
             const int tid = ptid(), l4 = tid & 15, hi = tid >> 4;
             const int b4s = l4 | (hi << 9);
@@ -536,6 +735,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
                 for (int q = 0; q < 32; ++q) y[q + 32 * g] = to_v(lds[tid + (q << 9)]);
             }
+        }
         }
         if constexpr (DMA) {
             dma_ready = k + 1 < k_end;
@@ -562,10 +762,10 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
             for (int q = 0; q < PH; ++q) tpre[q] = tail_ld((GV2)tsc + T * q + (unsigned)tt);
         }
-        constexpr bool FUSE = R == 64 && RC_B4_FUSE_LAST;
-        if constexpr (FUSE) {  // stages 9..m-2 on each half (the two halves share their twiddles)
+        if constexpr (OVL4) {
+        } else if constexpr (FUSE) {  // stages 9..m-2 on each half (the two halves share their twiddles)
             const v2f wfl = to_v(lds[T_A + ptid()]);
-            const v2f wf2 = vcmul(wfl, wfl);
+            const v2f wf2 = vcsq(wfl);
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 v2f grp[R / 2];
@@ -598,6 +798,12 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             // pair_regs_pk4 leaves the -1/(4N) of the magnitudes out (a power of two): it rides on the amplitude
             const float ak = p.amp * (-0.25f / (float)(1 << LOG2N));
             const v2f ampk = {ak, ak};
+            v2f hfE = hf;
+            if constexpr (HANN) {  // env[i] * amp = amp/2 + c_q (amp cb) + s_q (amp sb): the amplitude rides on the rotation
+                cbE *= ampk;
+                sbE *= ampk;
+                hfE = hf * ampk;
+            }
             const int64_t g0 = k * (int64_t)H;
             GFW dst = outc + (g0 / (int64_t)pitch - p.out_origin);
             const uint32_t kr = (uint32_t)(g0 % pitch);
@@ -637,12 +843,13 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                         const v2f wt = __builtin_elementwise_fma(v2f{HW.s[q0 + q + PH], HW.s[q0 + q + PH]}, sbW,
                                        __builtin_elementwise_fma(v2f{HW.c[q0 + q + PH], HW.c[q0 + q + PH]}, cbW, hf));
                         const v2f ev = __builtin_elementwise_fma(v2f{HE.s[q0 + q], HE.s[q0 + q]}, sbE,
-                                       __builtin_elementwise_fma(v2f{HE.c[q0 + q], HE.c[q0 + q]}, cbE, hf));
+                                       __builtin_elementwise_fma(v2f{HE.c[q0 + q], HE.c[q0 + q]}, cbE, hfE));
                         wr0[q] = wh.x, wr1[q] = wh.y, wt0[q] = wt.x, wt1[q] = wt.y, e0[q] = ev.x, e1[q] = ev.y;
                     }
                     if constexpr (TPRE) tq[q] = tpre[q0 + q];
                     else if constexpr (TAIL_GLOBAL) {}
-                    else tq[q] = tail[q0 + q];
+                    else if (q0 + q < PHR) tq[q] = tail[q0 + q];
+                    else tq[q] = to_v(lds[TLB + 512 * (q0 + q - PHR) + tt]);
                 }
 #pragma unroll
                 for (int q = 0; q < EB; ++q) {
@@ -660,7 +867,8 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                     const v2f nt = yt * v2f{wt0[q], wt1[q]};
                     if (k >= k_begin) {
                         // stretcher.rs:97-100 operation order
-                        const v2f o = (head + tq[q]) * v2f{e0[q], e1[q]} * ampk;
+                        // stretcher.rs:97-100; with the computed envelope the amplitude is already inside it
+                        const v2f o = HANN ? (head + tq[q]) * v2f{e0[q], e1[q]} : (head + tq[q]) * v2f{e0[q], e1[q]} * ampk;
                         if constexpr (PITCH1) {
                             if (!(RC_B4_ABL & 4) || o.x == 1.2345f)  // (bit 4, timing only: no output stores)
                             __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * (q0 + q) + lane2));
@@ -675,7 +883,8 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                         if (!(RC_B4_ABL & 2)) tail_st(tsc + T * (q0 + q) + (unsigned)tt, nt);
                         else if (nt.x == 1.2345f) stg2(tsc, to_f2(nt));  // (keeps nt alive)
                     }
-                    else tail[q0 + q] = nt;
+                    else if (q0 + q < PHR) tail[q0 + q] = nt;
+                    else lds[TLB + 512 * (q0 + q - PHR) + tt] = to_f2(nt);
                 }
                 // (register tail at R = 64: 192 registers are taken; keep the batches' window / twiddle temporaries apart)
                 if constexpr (!TAIL_GLOBAL && R > 32) __builtin_amdgcn_sched_barrier(0);

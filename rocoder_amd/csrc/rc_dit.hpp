@@ -20,6 +20,18 @@ __device__ __forceinline__ v2f vcmul(v2f a, v2f k) {  // a * k
     const v2f t = __builtin_shufflevector(a, a, 0, 0) * k;
     return __builtin_elementwise_fma(__builtin_shufflevector(a, a, 1, 1), v2f{-k.y, k.x}, t);
 }
+// a * a: with a runtime operand hipcc builds (-a.y, a.x) with a v_xor + v_mov in front of the FMA; as VOP3P source
+// modifiers (op_sel + neg_lo) the square is two instructions instead of four
+#ifndef RC_VCSQ
+#define RC_VCSQ 1
+#endif
+__device__ __forceinline__ v2f vcsq(v2f a) {
+    if (!RC_VCSQ) return vcmul(a, a);
+    const v2f t = __builtin_shufflevector(a, a, 0, 0) * a;
+    v2f r;  // t + a.yy * (-a.y, a.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(a), "v"(t));
+    return r;
+}
 
 // DIT stages S_LO..S_HI on NREG registers: register bit (s - REG_LO) <-> position bit s; the
 // position bits below REG_LO are the runtime value l (< 2^REG_LO; HAS_L = false means l == 0).
@@ -69,7 +81,7 @@ __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], v2f wfine = v2f{1.0f,
     if (HAS_L) {
         bases[S_HI - S_LO] = wfine;
 #pragma unroll
-        for (int s = S_HI - 1; s >= S_LO; --s) bases[s - S_LO] = vcmul(bases[s + 1 - S_LO], bases[s + 1 - S_LO]);
+        for (int s = S_HI - 1; s >= S_LO; --s) bases[s - S_LO] = vcsq(bases[s + 1 - S_LO]);
     }
 #pragma unroll
     for (int s = S_LO; s <= S_HI; ++s) {
