@@ -628,26 +628,43 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             opaque(t2);
             // F[t] = O[t * pitch] (src/resampler.rs:3-18): sample a = kr + i of this hop is kept iff a % pitch == 0,
             // at dst[a / pitch]. One division per hop and lane (q = 0); every further register pair is 2T = 512
-            // samples on: quotient and remainder advance by the uniform 512 / pitch and 512 % pitch
+            // samples on: quotient and remainder advance by the uniform 512 / pitch and 512 % pitch. The destination is
+            // a uniform base (SGPRs) + a 32-bit byte offset per lane, as for pitch 1: no 64-bit address per store.
+            // (Gathering a row's kept samples across the wave with ds_bpermute into ONE contiguous store per row, with
+            // or without a lane mask, was measured: 4.68 / 4.72 ms against 4.67 for C3 - the two sparse stores are not
+            // what pitch > 1 costs.)
+            // Branch-free: the stores are raw buffer stores whose offset is out of range for a lane that keeps nothing
+            // (the hardware drops it), so the epilogue stays ONE basic block - with an exec-masked branch around each of
+            // the 32 stores the allocator spilled 20 more registers (31 dwords in and out of scratch per hop and lane
+            // against 11 for pitch 1), and that, not the sparse stores, was what pitch > 1 cost.
+            const unsigned long long da = (unsigned long long)dst;
+            const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);
+            const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(((unsigned long long)dhi << 32) | dlo), 0, 0x40000000, 0x00020000);  // raw buffer, 1 GiB window
+            constexpr uint32_t DROP = 0xFFFFFFFCu;
             const uint32_t a00 = kr + 2u * (uint32_t)t2;
-            uint32_t d = a00 / pitch, r = a00 - d * pitch;
-            const uint32_t qs = (2u * T) / pitch, rs = (2u * T) - qs * pitch;
+            const uint32_t d0 = a00 / pitch;
+            uint32_t r = a00 - d0 * pitch, d4 = 4u * d0;
+            const uint32_t qs4 = 4u * ((2u * T) / pitch), rs = (2u * T) - (qs4 / 4u) * pitch;
 #pragma unroll
             for (int q = 0; q < PH; ++q) {
                 const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
                                __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
                 const v2f o = (head[q] + tail[q]) * er;
-                if (!(RC_ABLATE & 1024) || o.x == 1.2345e-30f) {  // (bit 1024, timing only: no output stores)
-                    if (r == 0) dst[d] = o.x;                 // a0 = d * pitch
-                    if (r + 1 == pitch) dst[d + 1] = o.y;     // a1 = a0 + 1 = (d + 1) * pitch
+                const float ox = o.x, oy = o.y;
+                if (!(RC_ABLATE & 1024) || ox == 1.2345e-30f) {  // (bit 1024, timing only: no output stores)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ox), rsrc, r == 0 ? d4 : DROP, 0, 0);  // a0 = d * pitch
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(oy), rsrc, r + 1 == pitch ? d4 + 4u : DROP, 0, 0);
                 }
-                d += qs;
+                d4 += qs4;
                 r += rs;
                 if (r >= pitch) {
                     r -= pitch;
-                    d += 1;
+                    d4 += 4u;
                 }
             }
+            // (one store per row - the two samples are never both kept - was measured too: 4.64-4.76 against 4.66-4.69 ms)
         }
     };
     // Deferred output stores (pitch 1). A CU drains about 11 bytes per clock towards memory: the 8 KiB a wave
