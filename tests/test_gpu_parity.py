@@ -15,6 +15,10 @@ from oracle import oracle_np as onp
 pytestmark = pytest.mark.gpu
 
 TOL = 1.0e-4
+# Regression gate: what the kernels actually deliver is 1.5e-7 .. 8e-7 of the signal's RMS (f32 FFT round-off); a change
+# that moves a path to 1e-5 is a bug even though the contract (TOL) still holds. Paths with a longer f32 chain pass
+# their own measured bound explicitly (`reg=`).
+REG_TOL = 2.0e-6
 
 
 def _engine_mod():
@@ -25,14 +29,29 @@ def _engine_mod():
     return rocoder_amd
 
 
-def assert_parity(got, ref, what=""):
+def assert_parity(got, ref, what="", reg=REG_TOL):
     got = np.asarray(got, np.float64)
     ref = np.asarray(ref, np.float64)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     err = rms(got - ref)
     r = rms(ref)
-    assert err <= TOL and err <= TOL * r + 1e-9, f"{what}: rms_err={err:.3e} rms_ref={r:.3e}"
+    assert err <= TOL and err <= TOL * r + 1e-9, f"{what}: rms_err={err:.3e} rms_ref={r:.3e}"  # the contract
+    assert err <= reg * r + 1e-9, f"{what}: REGRESSION rms_err={err:.3e} = {err / max(r, 1e-30):.2e} of rms_ref"
     return err
+
+
+def assert_blocks(got, ref, block, what="", bound=5.0e-6):
+    """No isolated bad stretch (one seam block, one run) hides inside a good global RMS: every block of `block`
+    samples of every channel is within `bound` of the channel's RMS."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    nb = got.shape[-1] // block
+    d = (got[..., :nb * block] - ref[..., :nb * block]).reshape(got.shape[:-1] + (nb, block))
+    blk = np.sqrt((d * d).mean(axis=-1))
+    scale = np.sqrt((ref * ref).mean(axis=-1, keepdims=True))
+    worst = float((blk / scale).max())
+    assert worst <= bound, (what, worst, np.unravel_index((blk / scale).argmax(), blk.shape))
+    return worst
 
 
 def _kernel_for(gain):
@@ -84,7 +103,9 @@ def test_stretch_matches_oracle(N, L, f, p, ch):
     got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=0x5EED)
     ref = oc.stretch_offline(x, N, f, 1.0, p, seed=0x5EED)
     for c in range(ch):
-        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}")
+        # (a plain N-term f32 sum per bin, twice: measured 2.3e-6 at N = 6000, 3e-6 at 12 000 - the FFT paths' gate
+        # of 2e-6 does not apply; 1e-5 is this path's regression gate)
+        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}", reg=1e-5)
 
 
 @pytest.mark.parametrize("N,L", [(256, 0), (256, 1), (256, 255), (256, 256), (256, 257),
@@ -141,7 +162,9 @@ def test_negative_pitch_multiples_match_oracle(N, L, f, p, ch):
     got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=0x5EED)
     ref = oc.stretch_offline(x, N, f, 1.0, p, seed=0x5EED)
     for c in range(ch):
-        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}")
+        # (a plain N-term f32 sum per bin, twice: measured 2.3e-6 at N = 6000, 3e-6 at 12 000 - the FFT paths' gate
+        # of 2e-6 does not apply; 1e-5 is this path's regression gate)
+        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}", reg=1e-5)
 
 
 def test_negative_pitch_with_kernel_and_streaming():
@@ -842,10 +865,59 @@ def test_16384_full_length_every_sample_vs_oracle(p):
         assert_parity(got[c], ref[c], f"full length p={p} ch{c}")
     # no isolated bad stretch hides inside a good global RMS: per-half-window blocks too
     H = N // 2 // p if (N // 2) % p == 0 else N // 2
-    nb = got.shape[1] // H
-    d = (got[:, :nb * H].astype(np.float64) - ref[:, :nb * H]).reshape(2, nb, H)
-    blk = np.sqrt((d * d).mean(axis=2))
-    assert blk.max() <= 3e-4, (float(blk.max()), np.unravel_index(blk.argmax(), blk.shape))
+    assert_blocks(got, ref, H, f"full length p={p}")
+
+
+@pytest.mark.parametrize("case", ["table_window_pitch3", "three_channels"])
+def test_16384_full_length_other_kernel_paths(case):
+    """The same every-sample check on the paths the default-window stereo job does not take: (a) C3's geometry
+    (pitch 3) with a caller-supplied window - hop2_kernel's table variant, decimating stores included; (b) three
+    channels at L >= 3 M - an odd channel count through hop4's per-XCD run tickets and seam hand-overs."""
+    import torch
+
+    ra = _engine_mod()
+    N, f, seed = 16384, 8.0, 0xBEEF
+    if case == "table_window_pitch3":
+        ch, L, p = 2, 1_200_000, 3
+        w = (oc.hanning(N).astype(np.float64) ** 1.5).astype(np.float32)  # not the default window: table path
+        kw = dict(window=w)
+    else:
+        ch, L, p = 3, 3_000_000, 1
+        w, kw = None, {}
+    x = np.stack([onp.synth_input(c, L) for c in range(ch)])
+    with ra.Engine(window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=seed, **kw) as e:
+        got = e.stretch_tensor(torch.from_numpy(x).cuda()).cpu().numpy()
+    if w is None:
+        ref = oc.stretch_offline(x, N, f, 1.0, p, seed=seed)
+    else:  # (the offline helper always takes windows::hanning: drive one oracle Stretcher per channel)
+        chans = []
+        for c in range(ch):
+            st = oc.Stretcher(channels=ch, factor=f, pitch_multiple=p, window=w, seed=seed, channel_index=c)
+            st.send(x[c])
+            st.close_input()
+            wins = []
+            while not st.is_done():
+                wins.append(st.next_window())
+            chans.append(np.concatenate(wins))
+        ref = np.stack(chans)
+    assert got.shape == ref.shape
+    for c in range(ch):
+        assert_parity(got[c], ref[c], f"{case} ch{c}")
+    assert_blocks(got, ref, N // 2 if p == 1 else N // 2, case)
+
+
+def test_c5_geometry_every_sample_vs_oracle():
+    """BASELINE C5's geometry (window 65536, factor 32: big4_kernel<64>, tail in registers / LDS, overlapped
+    exchange rounds) against the oracle on EVERY sample at a length the oracle can afford: 2 channels x 600 000."""
+    ra = _engine_mod()
+    N, f, L, seed = 65536, 32.0, 600_000, 0x5EED
+    x = np.stack([onp.synth_input(c, L) for c in range(2)])
+    got = ra.stretch(x, window_len=N, factor=f, seed=seed)
+    ref = oc.stretch_offline(x, N, f, 1.0, 1, seed=seed)
+    assert got.shape == ref.shape
+    for c in range(2):
+        assert_parity(got[c], ref[c], f"C5 geometry ch{c}")
+    assert_blocks(got, ref, N // 2, "C5 geometry")
 
 
 @pytest.mark.parametrize("p", [1, 3])
@@ -967,7 +1039,9 @@ def test_window_lengths_that_are_not_powers_of_two(N, L, f, p, ch):
     got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=0x5EED)
     ref = oc.stretch_offline(x, N, f, 1.0, p, seed=0x5EED)
     for c in range(ch):
-        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}")
+        # (a plain N-term f32 sum per bin, twice: measured 2.3e-6 at N = 6000, 3e-6 at 12 000 - the FFT paths' gate
+        # of 2e-6 does not apply; 1e-5 is this path's regression gate)
+        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}", reg=1e-5)
 
 
 def test_non_power_of_two_window_refft_device_kernel_and_streaming():
