@@ -103,9 +103,7 @@ def test_stretch_matches_oracle(N, L, f, p, ch):
     got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=0x5EED)
     ref = oc.stretch_offline(x, N, f, 1.0, p, seed=0x5EED)
     for c in range(ch):
-        # (a plain N-term f32 sum per bin, twice: measured 2.3e-6 at N = 6000, 3e-6 at 12 000 - the FFT paths' gate
-        # of 2e-6 does not apply; 1e-5 is this path's regression gate)
-        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}", reg=1e-5)
+        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}")
 
 
 @pytest.mark.parametrize("N,L", [(256, 0), (256, 1), (256, 255), (256, 256), (256, 257),
@@ -162,9 +160,7 @@ def test_negative_pitch_multiples_match_oracle(N, L, f, p, ch):
     got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=0x5EED)
     ref = oc.stretch_offline(x, N, f, 1.0, p, seed=0x5EED)
     for c in range(ch):
-        # (a plain N-term f32 sum per bin, twice: measured 2.3e-6 at N = 6000, 3e-6 at 12 000 - the FFT paths' gate
-        # of 2e-6 does not apply; 1e-5 is this path's regression gate)
-        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}", reg=1e-5)
+        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}")
 
 
 def test_negative_pitch_with_kernel_and_streaming():
