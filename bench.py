@@ -238,6 +238,9 @@ def main():
         ev1.record(stream)
         barrier()
         dt = time.perf_counter() - t0
+        # a kernel that gave up inside the timed region (seam wait expired: output incomplete) reports through the
+        # engine's device error word; synchronize() raises it. A line measured on such a run must not be printed.
+        eng.synchronize()
         step_event_ms = ev0.elapsed_time(ev1) / args.steps
         # per-launch kernel durations of exactly those steps (the engine brackets each kernel launch)
         per_call = eng.kernel_times(min(64, args.steps * max(1, len(mine))))
@@ -370,11 +373,19 @@ def main():
             emitted[0] = True
 
     def watchdog():
+        # The main line is printed (it is complete), then the process exits NON-ZERO: a collective that hung on
+        # GPU-initialised processes must be visible to the launcher, not look like a clean run.
         nonlocal concat
-        if not emitted[0]:
-            concat = {"error": f"the post-measurement extras (C5 shards, concat) did not finish within {CONCAT_TIMEOUT_S} s; the main line is unaffected"}
-        emit()
-        os._exit(0)
+        with lock:
+            if rank == 0 and not emitted[0]:
+                res["config"]["concat"] = concat or {
+                    "error": f"the post-measurement extras (C5 shards, concat) did not finish within "
+                             f"{CONCAT_TIMEOUT_S} s; the main line is unaffected"}
+                if c5:
+                    res["config"]["c5_sharded"] = c5
+                os.write(real_stdout, (json.dumps(res) + "\n").encode())
+            emitted[0] = True
+        os._exit(3)
 
     timer = threading.Timer(CONCAT_TIMEOUT_S, watchdog)
     timer.daemon = True

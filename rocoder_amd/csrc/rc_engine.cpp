@@ -17,10 +17,32 @@
 #include <deque>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
 namespace {
+// Worker threads that are always joined: if a later std::thread constructor throws (std::system_error), the ones
+// already started must not be destroyed joinable (std::terminate) - the C ABI's catch (...) turns the failure into
+// RC_E* only if unwinding gets that far.
+struct JoinedThreads {
+    std::vector<std::thread> th;
+    template <class F, class... A>
+    bool start(F &&f, A &&...a) {  // false: could not start (the caller runs that share itself)
+        try {
+            th.emplace_back(std::forward<F>(f), std::forward<A>(a)...);
+            return true;
+        } catch (const std::system_error &) {
+            return false;
+        }
+    }
+    void join() {
+        for (auto &t : th)
+            if (t.joinable()) t.join();
+        th.clear();
+    }
+    ~JoinedThreads() { join(); }
+};
 
 thread_local std::string g_err;
 
@@ -449,11 +471,13 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
         if (nthr <= 1) {
             apply_range(0, n_channels);  // the reference's single DSP thread and call order
         } else {  // rc_config::kernel_threads: channels dealt to threads, per-channel hop order kept
-            std::vector<std::thread> pool;
-            for (uint32_t t = 1; t < nthr; ++t)
-                pool.emplace_back(apply_range, n_channels * t / nthr, n_channels * (t + 1) / nthr);
+            JoinedThreads pool;
+            for (uint32_t t = 1; t < nthr; ++t) {
+                const uint32_t c0 = n_channels * t / nthr, c1 = n_channels * (t + 1) / nthr;
+                if (!pool.start(apply_range, c0, c1)) apply_range(c0, c1);  // (no thread to be had: this one does it)
+            }
             apply_range(0, n_channels / nthr);
-            for (auto &th : pool) th.join();
+            pool.join();
         }
         RC_HIP(hipMemcpyAsync(kp.d_spec[set].p, kp.h_out[set], (size_t)kc * hop_bytes,
                               hipMemcpyHostToDevice, kp.kb));
@@ -549,7 +573,6 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
                 return fail(RC_EINVAL, "a user kernel carries the overlap tail: channel %u continues at hop %lld "
                                        "(or restarts at 0), not at %lld", c, (long long)e->kernel_next_hop[c],
                             (long long)hop_first);
-        for (uint32_t c = ch_first; c < ch_first + n_channels; ++c) e->kernel_next_hop[c] = hop_first + hop_count;
     }
     if (e->last_valid && e->last_stream != s) RC_HIP(hipStreamWaitEvent(s, e->ev_last, 0));
     struct MarkLast {  // whatever path returns: the next call orders itself behind this one
@@ -881,7 +904,8 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     if (e->cfg.kernel) {
         if ((rc = run_hops_kernel(e, p, ch_first, n_channels, hop_first, hop_count, d_out, out_stride,
                                   out_origin, s, &launches)))
-            return rc;
+            return rc;  // (kernel_next_hop untouched: the caller may retry the same range)
+        for (uint32_t c = ch_first; c < ch_first + n_channels; ++c) e->kernel_next_hop[c] = hop_first + hop_count;
     } else
     for (int64_t k0 = hop_first; k0 < hop_first + hop_count; k0 += chunk_max) {
         const int64_t kc = std::min<int64_t>(chunk_max, hop_first + hop_count - k0);
@@ -1429,10 +1453,12 @@ int host_copy(rc_engine *e, bool to_device, float *const *host, float *dev, size
             }
         }
     };
-    std::vector<std::thread> th;
-    for (int w = 1; w < workers; ++w) th.emplace_back(work, w);
-    work(0);
-    for (auto &t : th) t.join();
+    JoinedThreads th;
+    std::vector<int> mine{0};  // worker slots this thread serves itself (slot 0 + any whose thread did not start)
+    for (int w = 1; w < workers; ++w)
+        if (!th.start(work, w)) mine.push_back(w);
+    for (int w : mine) work(w);
+    th.join();
     if (err.load()) return fail(RC_EHIP, "host copy: %s", hipGetErrorString(hipGetLastError()));
     // (H2D: every worker synchronised its stream, so whatever is launched on e->stream next sees the data)
     return RC_OK;

@@ -72,12 +72,15 @@ def stretch_sharded(compute: Callable[..., "object"], channels: int, total_windo
     computes its own shards INTO their views of it; every other shard travels as one message into its
     view (grouped send / recv to the root, or one broadcast per shard when every rank wants the
     result). No padding to the longest segment, no staging list, no block-by-block re-copy.
-    `full` may be passed in (reused across calls); it must be contiguous."""
+    `full` may be passed in (reused across calls); it must be contiguous.
+    `dst` is a rank OF `group` (0 .. group size - 1), like the `rank` fields of the shard plan - not a global rank;
+    with a sub-group, translate a global rank with `dist.get_group_rank(group, global_rank)` first."""
     import torch
     import torch.distributed as dist
 
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
+    assert dst is None or 0 <= dst < world, f"dst={dst} is not a rank of the group (size {world})"
     plan = shard_plan(channels, total_windows, world)
     holds_full = dst is None or rank == dst
     width = total_windows * window_out_len

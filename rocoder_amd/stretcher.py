@@ -211,7 +211,10 @@ class Engine:
                                                      C.c_void_p(stream)))
 
     def stretch_tensor(self, x, out=None, stream=None):
-        """x: torch float32 CUDA tensor [channels, L] (device-resident). Returns [channels, n_out]."""
+        """x: torch float32 CUDA tensor [channels, L] (device-resident). Returns [channels, n_out].
+        Asynchronous on the caller's stream: a device-side failure (a run-seam wait that expired leaves samples
+        unwritten) is raised by the NEXT call on this engine - call `synchronize()` once the stream is synced
+        before trusting `out` when no further call follows."""
         import torch
 
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
