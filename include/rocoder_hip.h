@@ -190,6 +190,40 @@ int rc_engine_forward_fft(rc_engine *e, const float *samples, float *out_reim);
 int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float *samples,
                       float *out);
 
+/* ---- one process, several GPUs of one node ---------------------------------------------------
+ * The reference builds every channel's Stretcher in one process (src/main.rs:133-155) and one thread walks them
+ * (src/stretcher_processor.rs:56-71). rc_multi is that job cut over a LIST of devices behind the same C-ABI: one
+ * engine and one host thread per listed device, the channel-major sequence of output windows cut into one contiguous
+ * piece per device (rc_shard_plan: SURVEY 8 e1's (channel, window range) units; the hop before a piece is
+ * recomputed locally, no data-path collective), and every shard's output copied ONCE, straight into its place in the
+ * caller's layout (device form: hipMemcpyPeerAsync into the root device's tensor; host form: device -> the caller's
+ * arrays). A host frequency kernel (rc_config::kernel) is RC_EUNSUPPORTED here: a stateful apply() sees its
+ * channel's hops in order, which a cut job cannot promise; the curated device kernels work. rc_config::device is
+ * ignored. A device may be listed more than once (then its engines share it). */
+typedef struct rc_shard {
+    uint32_t device_index;        /* index into the device list */
+    uint32_t ch_first, ch_count;  /* part of ONE channel, or a block of WHOLE channels */
+    uint64_t win_first, win_count;
+} rc_shard;
+/* Pure host: the plan for `channels` x `total_windows` windows over `n_devices`; writes up to `cap` shards, returns
+ * how many the plan has (at most 3 per device). */
+size_t rc_shard_plan(uint32_t channels, uint64_t total_windows, uint32_t n_devices, rc_shard *out, size_t cap);
+
+typedef struct rc_multi rc_multi;
+int rc_multi_create(const rc_config *cfg, const int32_t *device_ids, uint32_t n_devices, rc_multi **out);
+void rc_multi_destroy(rc_multi *m);
+uint32_t rc_multi_device_count(const rc_multi *m);
+/* rc_engine_stretch_host over all listed devices: each uploads the span of input its shards read and downloads
+ * its shards into out[c]. Blocking. */
+int rc_multi_stretch_host(rc_multi *m, const float *const *in, size_t in_len, float *const *out, size_t out_cap,
+                          size_t *out_len);
+/* rc_engine_stretch_device with input and output resident on device_ids[root] (channel c at base + c * stride,
+ * strides in floats): the other devices fetch the input span they need from the root and deliver their shards into
+ * d_out by peer copies. `hip_stream` (a hipStream_t of the root device, or NULL) is what produced d_in: it is
+ * synchronised on entry. Blocking: d_out is complete on return. */
+int rc_multi_stretch_device(rc_multi *m, uint32_t root, const float *d_in, size_t in_stride, size_t in_len,
+                            float *d_out, size_t out_stride, size_t out_cap, size_t *out_len, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

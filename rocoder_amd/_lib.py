@@ -65,6 +65,16 @@ class rc_params(C.Structure):
     ]
 
 
+class rc_shard(C.Structure):
+    _fields_ = [
+        ("device_index", C.c_uint32),
+        ("ch_first", C.c_uint32),
+        ("ch_count", C.c_uint32),
+        ("win_first", C.c_uint64),
+        ("win_count", C.c_uint64),
+    ]
+
+
 # every symbol include/rocoder_hip.h declares: name -> (restype, argtypes)
 _fp = C.POINTER(C.c_float)
 _sz = C.c_size_t
@@ -100,6 +110,13 @@ SYMBOLS = {
     "rc_engine_kernel_times": (C.c_int, [_eng, _fp, _sz, C.POINTER(_sz)]),
     "rc_engine_forward_fft": (C.c_int, [_eng, _fp, _fp]),
     "rc_engine_resynth": (C.c_int, [_eng, C.c_uint32, C.c_uint64, _fp, _fp]),
+    "rc_shard_plan": (_sz, [C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(rc_shard), _sz]),
+    "rc_multi_create": (C.c_int, [C.POINTER(rc_config), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(_eng)]),
+    "rc_multi_destroy": (None, [_eng]),
+    "rc_multi_device_count": (C.c_uint32, [_eng]),
+    "rc_multi_stretch_host": (C.c_int, [_eng, C.POINTER(_fp), _sz, C.POINTER(_fp), _sz, C.POINTER(_sz)]),
+    "rc_multi_stretch_device": (C.c_int, [_eng, C.c_uint32, C.c_void_p, _sz, _sz, C.c_void_p, _sz, _sz,
+                                          C.POINTER(_sz), C.c_void_p]),
 }
 
 _lib = None

@@ -15,6 +15,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
+#include <memory>
 #include <new>
 #include <string>
 #include <system_error>
@@ -1606,6 +1608,231 @@ int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float 
     RC_HIP(hipMemcpyAsync(out, e->d_ybuf.p, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     RC_HIP(hipStreamSynchronize(e->stream));
     return RC_OK;
+} catch (...) {
+    return rc_catch();
+}
+
+// ================================ several devices, one process ====================================
+// (include/rocoder_hip.h, rc_multi). The plan is rocoder_amd/distributed.py::shard_plan in C++; the multi-process
+// layer (one process per GPU over torch.distributed / RCCL) and this one cut a job identically.
+size_t rc_shard_plan(uint32_t channels, uint64_t total_windows, uint32_t n_devices, rc_shard *out, size_t cap) {
+    if (channels == 0 || n_devices == 0) return 0;
+    size_t n = 0;
+    const unsigned __int128 total = (unsigned __int128)channels * total_windows;
+    for (uint32_t r = 0; r < n_devices; ++r) {
+        uint64_t lo = (uint64_t)(total * r / n_devices), hi = (uint64_t)(total * (r + 1) / n_devices);
+        while (lo < hi) {
+            const uint32_t c = (uint32_t)(lo / total_windows);
+            const uint64_t w0 = lo % total_windows;
+            uint64_t w1 = std::min<uint64_t>(total_windows, w0 + (hi - lo));
+            uint32_t cc = 1;
+            lo += w1 - w0;
+            if (w0 == 0 && w1 == total_windows)  // merge the whole channels that follow
+                while (hi - lo >= total_windows) {
+                    ++cc;
+                    lo += total_windows;
+                }
+            if (out && n < cap) out[n] = rc_shard{r, c, cc, w0, w1 - w0};
+            ++n;
+        }
+    }
+    return n;
+}
+
+struct rc_multi {
+    rc_config cfg{};
+    rc_params par{};
+    std::vector<int> dev;
+    std::vector<rc_engine *> eng;
+    std::vector<hipStream_t> st;
+    std::vector<DevBuf> d_in, d_out;  // per listed device: its input span and its shards (non-root / host form)
+};
+
+namespace {
+struct WorkerResult {
+    int rc = RC_OK;
+    std::string msg;
+};
+// Runs fn(i) on one thread per listed device (the caller's thread takes device 0's share) and folds the results:
+// the first failure, with its thread's rc_last_error text re-posted on the calling thread.
+int for_each_device(rc_multi *m, const std::function<int(size_t)> &fn) {
+    const size_t n = m->eng.size();
+    std::vector<WorkerResult> res(n);
+    auto run = [&](size_t i) {
+        int rc;
+        try {
+            rc = fn(i);
+        } catch (...) {
+            rc = rc_catch();
+        }
+        res[i].rc = rc;
+        if (rc != RC_OK) res[i].msg = g_err;
+    };
+    {
+        JoinedThreads th;
+        std::vector<size_t> mine{0};
+        for (size_t i = 1; i < n; ++i)
+            if (!th.start(run, i)) mine.push_back(i);
+        for (size_t i : mine) run(i);
+        th.join();
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (res[i].rc != RC_OK) return fail(res[i].rc, "device %d (list index %zu): %s", m->dev[i], i, res[i].msg.c_str());
+    return RC_OK;
+}
+// samples [lo, hi) of the input that the hops of windows [w0, w1) read, incl. the recomputed hop before them
+void input_span(const rc_params &p, uint64_t w0, uint64_t w1, size_t in_len, size_t *lo, size_t *hi) {
+    const uint64_t h0 = w0 * p.hops_per_window, h1 = w1 * p.hops_per_window;
+    const uint64_t first = h0 > 0 ? h0 - 1 : 0;
+    const uint64_t a = first * p.sample_step_len, b = (h1 - 1) * p.sample_step_len + p.window_len;
+    *lo = (size_t)std::min<uint64_t>(a, in_len);
+    *hi = (size_t)std::min<uint64_t>(b, in_len);
+}
+}  // namespace
+
+int rc_multi_create(const rc_config *cfg, const int32_t *device_ids, uint32_t n_devices, rc_multi **out) try {
+    if (!cfg || !out || !device_ids || n_devices == 0) return fail(RC_EINVAL, "null argument or empty device list");
+    *out = nullptr;
+    if (cfg->kernel)
+        return fail(RC_EUNSUPPORTED, "a host frequency kernel sees its channel's hops in order (src/fft.rs:76-108): "
+                                     "not on a job cut over devices; use one engine or a device kernel");
+    std::unique_ptr<rc_multi, void (*)(rc_multi *)> m(new rc_multi, rc_multi_destroy);
+    m->cfg = *cfg;
+    if (int rc = rc_derive_params(cfg, &m->par)) return rc;
+    for (uint32_t i = 0; i < n_devices; ++i) {
+        rc_config c = *cfg;
+        c.device = device_ids[i];
+        rc_engine *e = nullptr;
+        if (int rc = rc_engine_create(&c, &e)) return rc;
+        m->dev.push_back(device_ids[i]);
+        m->eng.push_back(e);
+        m->st.push_back(nullptr);
+        RC_HIP(hipSetDevice(device_ids[i]));
+        RC_HIP(hipStreamCreateWithFlags(&m->st.back(), hipStreamNonBlocking));
+    }
+    m->d_in.resize(n_devices);
+    m->d_out.resize(n_devices);
+    for (uint32_t i = 0; i < n_devices; ++i)  // peer access where the hardware has it (copies work without)
+        for (uint32_t j = 0; j < n_devices; ++j)
+            if (m->dev[i] != m->dev[j]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, m->dev[i], m->dev[j]) == hipSuccess && can) {
+                    (void)hipSetDevice(m->dev[i]);
+                    (void)hipDeviceEnablePeerAccess(m->dev[j], 0);  // (already enabled: an error we ignore)
+                    (void)hipGetLastError();
+                }
+            }
+    *out = m.release();
+    return RC_OK;
+} catch (...) {
+    return rc_catch();
+}
+
+void rc_multi_destroy(rc_multi *m) {
+    if (!m) return;
+    for (size_t i = 0; i < m->eng.size(); ++i) {
+        (void)hipSetDevice(m->dev[i]);
+        if (i < m->st.size() && m->st[i]) {
+            (void)hipStreamSynchronize(m->st[i]);
+            (void)hipStreamDestroy(m->st[i]);
+        }
+        if (i < m->d_in.size()) m->d_in[i].release();
+        if (i < m->d_out.size()) m->d_out[i].release();
+        rc_engine_destroy(m->eng[i]);
+    }
+    delete m;
+}
+
+uint32_t rc_multi_device_count(const rc_multi *m) { return m ? (uint32_t)m->eng.size() : 0; }
+
+namespace {
+// one device's share of the job. src: where channel c's sample 0 lives (root device or host), with its stride;
+// dst likewise for the output. host = both are host memory.
+int multi_share(rc_multi *m, size_t i, const std::vector<rc_shard> &plan, bool host, int root_dev,
+                const float *src, size_t src_stride, const float *const *src_rows, size_t in_len, float *dst,
+                size_t dst_stride, float *const *dst_rows, bool is_root) {
+    const int dev = m->dev[i];
+    rc_engine *e = m->eng[i];
+    hipStream_t s = m->st[i];
+    const uint64_t wout = m->par.window_out_len;
+    const uint32_t hpw = m->par.hops_per_window;
+    RC_HIP(hipSetDevice(dev));
+    for (const rc_shard &sh : plan) {
+        if (sh.device_index != i || sh.win_count == 0) continue;
+        const size_t n_sh = (size_t)(sh.win_count * wout);
+        if (is_root && !host) {  // input and output already live here: compute straight into the final place
+            int rc = run_hops(e, src + (size_t)sh.ch_first * src_stride, src_stride, 0, (int64_t)in_len, sh.ch_first,
+                              sh.ch_count, (int64_t)(sh.win_first * hpw), (int64_t)(sh.win_count * hpw),
+                              dst + (size_t)sh.ch_first * dst_stride + (size_t)(sh.win_first * wout), dst_stride,
+                              (int64_t)(sh.win_first * wout), s, true);
+            if (rc) return rc;
+            continue;
+        }
+        size_t lo, hi;
+        input_span(m->par, sh.win_first, sh.win_first + sh.win_count, in_len, &lo, &hi);
+        const size_t span = hi - lo;
+        if (int rc = m->d_in[i].reserve(std::max<size_t>(1, (size_t)sh.ch_count * span) * sizeof(float))) return rc;
+        if (int rc = m->d_out[i].reserve((size_t)sh.ch_count * n_sh * sizeof(float))) return rc;
+        float *li = (float *)m->d_in[i].p, *lo_ = (float *)m->d_out[i].p;
+        for (uint32_t c = 0; c < sh.ch_count && span; ++c) {
+            const float *from = host ? src_rows[sh.ch_first + c] + lo : src + (size_t)(sh.ch_first + c) * src_stride + lo;
+            if (host) RC_HIP(hipMemcpyAsync(li + (size_t)c * span, from, span * sizeof(float), hipMemcpyHostToDevice, s));
+            else RC_HIP(hipMemcpyPeerAsync(li + (size_t)c * span, dev, from, root_dev, span * sizeof(float), s));
+        }
+        // the local buffer holds samples [lo, hi) of each channel: in_origin = lo, and the samples that exist end at
+        // in_len (a window running past it is zero-padded by the engine as in the whole job)
+        int rc = run_hops(e, li, span, (int64_t)lo, (int64_t)in_len - (int64_t)lo, sh.ch_first, sh.ch_count,
+                          (int64_t)(sh.win_first * hpw), (int64_t)(sh.win_count * hpw), lo_, n_sh,
+                          (int64_t)(sh.win_first * wout), s, true);
+        if (rc) return rc;
+        for (uint32_t c = 0; c < sh.ch_count; ++c) {
+            float *to = host ? dst_rows[sh.ch_first + c] + (size_t)(sh.win_first * wout)
+                             : dst + (size_t)(sh.ch_first + c) * dst_stride + (size_t)(sh.win_first * wout);
+            if (host) RC_HIP(hipMemcpyAsync(to, lo_ + (size_t)c * n_sh, n_sh * sizeof(float), hipMemcpyDeviceToHost, s));
+            else RC_HIP(hipMemcpyPeerAsync(to, root_dev, lo_ + (size_t)c * n_sh, dev, n_sh * sizeof(float), s));
+        }
+        RC_HIP(hipStreamSynchronize(s));  // (the local buffers are reused by this device's next shard)
+    }
+    RC_HIP(hipStreamSynchronize(s));
+    return check_device_error(e);
+}
+}  // namespace
+
+int rc_multi_stretch_host(rc_multi *m, const float *const *in, size_t in_len, float *const *out, size_t out_cap,
+                          size_t *out_len) try {
+    if (!m || !in || !out) return fail(RC_EINVAL, "null argument");
+    const uint64_t total_win = offline_windows(m->par, in_len);
+    const size_t n_out = (size_t)(total_win * m->par.window_out_len);
+    if (out_cap < n_out) return fail(RC_ECAPACITY, "out_cap %zu < %zu", out_cap, n_out);
+    std::vector<rc_shard> plan(3 * m->eng.size());
+    plan.resize(rc_shard_plan(m->cfg.channels, total_win, (uint32_t)m->eng.size(), plan.data(), plan.size()));
+    int rc = for_each_device(m, [&](size_t i) {
+        return multi_share(m, i, plan, true, 0, nullptr, 0, in, in_len, nullptr, 0, out, false);
+    });
+    if (rc == RC_OK && out_len) *out_len = n_out;
+    return rc;
+} catch (...) {
+    return rc_catch();
+}
+
+int rc_multi_stretch_device(rc_multi *m, uint32_t root, const float *d_in, size_t in_stride, size_t in_len,
+                            float *d_out, size_t out_stride, size_t out_cap, size_t *out_len, void *hip_stream) try {
+    if (!m || !d_out || (!d_in && in_len)) return fail(RC_EINVAL, "null argument");
+    if (root >= m->eng.size()) return fail(RC_EINVAL, "root %u is not an index of the device list", root);
+    const uint64_t total_win = offline_windows(m->par, in_len);
+    const size_t n_out = (size_t)(total_win * m->par.window_out_len);
+    if (out_cap < n_out) return fail(RC_ECAPACITY, "out_cap %zu < %zu", out_cap, n_out);
+    RC_HIP(hipSetDevice(m->dev[root]));
+    if (hip_stream) RC_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+    std::vector<rc_shard> plan(3 * m->eng.size());
+    plan.resize(rc_shard_plan(m->cfg.channels, total_win, (uint32_t)m->eng.size(), plan.data(), plan.size()));
+    const int root_dev = m->dev[root];
+    int rc = for_each_device(m, [&](size_t i) {
+        return multi_share(m, i, plan, false, root_dev, d_in, in_stride, nullptr, in_len, d_out, out_stride, nullptr,
+                           i == root);
+    });
+    if (rc == RC_OK && out_len) *out_len = n_out;
+    return rc;
 } catch (...) {
     return rc_catch();
 }

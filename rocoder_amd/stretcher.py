@@ -264,6 +264,69 @@ class Engine:
         return out
 
 
+
+class MultiEngine:
+    """One process, several GPUs of one node (include/rocoder_hip.h, rc_multi): one engine + one host thread per
+    listed device, the job cut by `rc_shard_plan`, every shard copied once into its place. The multi-PROCESS layer
+    (one rank per GPU over torch.distributed / RCCL) is `rocoder_amd.distributed`; both cut a job identically."""
+
+    def __init__(self, device_ids: Sequence[int], **kw):
+        self._L = _lib.lib()
+        self._check = functools.partial(check, L=self._L)
+        self._cfg, self._keep = make_config(**kw)
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        self._check(self._L.rc_multi_create(C.byref(self._cfg), ids, len(device_ids), C.byref(h)))
+        self._h = h
+        self.channels = int(self._cfg.channels)
+        self.params = derive_params(**kw)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rc_multi_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def output_len(self, in_len: int) -> int:
+        return int(self._L.rc_offline_output_len(C.byref(self._cfg), in_len))
+
+    def stretch_host(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float32)
+        assert x.shape[0] == self.channels
+        n_out = self.output_len(x.shape[1])
+        out = np.empty((self.channels, n_out), np.float32)
+        fp = C.POINTER(C.c_float)
+        ins = (fp * self.channels)(*[r.ctypes.data_as(fp) for r in x])
+        outs = (fp * self.channels)(*[r.ctypes.data_as(fp) for r in out])
+        got = C.c_size_t(0)
+        self._check(self._L.rc_multi_stretch_host(self._h, ins, x.shape[1], outs, n_out, C.byref(got)))
+        assert got.value == n_out
+        return out
+
+    def stretch_tensor(self, x, out=None, root: int = 0):
+        """x, out: torch float32 CUDA tensors on the ROOT device of the list. Blocking."""
+        import torch
+
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        n_out = self.output_len(x.shape[1])
+        if out is None:
+            out = torch.empty((self.channels, n_out), dtype=torch.float32, device=x.device)
+        got = C.c_size_t(0)
+        s = torch.cuda.current_stream(x.device)
+        s.synchronize()
+        self._check(self._L.rc_multi_stretch_device(self._h, root, C.c_void_p(x.data_ptr()), x.stride(0), x.shape[1],
+                                                   C.c_void_p(out.data_ptr()), out.stride(0), out.shape[1],
+                                                   C.byref(got), None))
+        return out
+
+
 class ReFFT:
     """src/fft.rs ReFFT: `new(window, kernel_src)`, `forward_fft`, `resynth`. The unseedable
     thread_rng of src/fft.rs:64 is replaced by the (seed, channel, hop) phase key."""

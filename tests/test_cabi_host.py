@@ -134,3 +134,48 @@ def test_product_path_never_touches_the_oracle():
                 for pat in (r"^\s*(from|import)\s+oracle", r"#include\s*[\"<][^\n]*oracle",
                             r"librocoder_oracle", r"rco_[a-z_]+\s*\(", r"oracle[/.](cbind|oracle_np)"):
                     assert not re.search(pat, txt, flags=re.M), (os.path.join(dp, fn), pat)
+
+
+def test_shard_plan_of_the_library_equals_the_python_plan():
+    """rc_shard_plan (C++, the one-process multi-device layer) and rocoder_amd.distributed.shard_plan (one process
+    per GPU) must cut a job identically: same shards, same order."""
+    from rocoder_amd.distributed import shard_plan
+
+    L = _lib.lib()
+    for channels in (1, 2, 3, 8):
+        for windows in (0, 1, 2, 7, 322, 5106, 25826):
+            for n in (1, 2, 3, 4, 8):
+                py = shard_plan(channels, windows, n)
+                buf = (_lib.rc_shard * (3 * n))()
+                cnt = L.rc_shard_plan(channels, windows, n, buf, 3 * n)
+                got = [(s.device_index, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in buf[:cnt]]
+                want = [(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in py]
+                assert got == want, (channels, windows, n, got, want)
+                assert L.rc_shard_plan(channels, windows, n, None, 0) == cnt  # (count-only call)
+
+
+def test_abi_struct_layout_matches_the_committed_table_and_the_ctypes_mirror(tmp_path):
+    """The structs that cross the C-ABI, field by field: offsets and sizes printed by a C program compiled against
+    the header (tools/abi_layout.c) == tests/golden/abi_layout.json (the table INTEGRATION.md shows beside the Rust
+    #[repr(C)] structs) == the ctypes Structures of rocoder_amd/_lib.py. A field added, reordered or resized without
+    updating a binding fails here, not in a maintainer's build."""
+    import json
+    import subprocess
+
+    exe = tmp_path / "abi_layout"
+    subprocess.run(["gcc", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", str(exe),
+                    os.path.join(ROOT, "tools", "abi_layout.c")], check=True)
+    now = json.loads(subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout)
+    committed = json.load(open(os.path.join(ROOT, "tests", "golden", "abi_layout.json")))
+    assert now == committed, "include/rocoder_hip.h changed layout: regenerate tests/golden/abi_layout.json + INTEGRATION.md"
+    for name, st in (("rc_config", _lib.rc_config), ("rc_params", _lib.rc_params), ("rc_shard", _lib.rc_shard)):
+        table = dict(committed[name])
+        size, align = table.pop("sizeof")
+        assert C.sizeof(st) == size and C.alignment(st) == align, name
+        assert [f[0] for f in st._fields_] == list(table), name  # same fields, same order
+        for fname, _t in st._fields_:
+            d = getattr(st, fname)
+            assert [d.offset, d.size] == table[fname], (name, fname)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for fname, (off, size) in ((k, v) for k, v in committed["rc_config"].items() if k != "sizeof"):
+        assert f"| `{fname}` | {off} | {size} |" in text, f"INTEGRATION.md's rc_config table lacks {fname} @ {off}"
