@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 2
+#define RC_ABI_VERSION 3 /* 3: + rc_shard_plan / rc_multi_* (struct layouts unchanged since 2) */
 
 /* status codes */
 #define RC_OK 0
