@@ -144,8 +144,9 @@ Audio read_wav(FILE *f) {
         if (!r.read(ch, 8)) break;
         const uint32_t len = le32(ch + 4);
         if (!memcmp(ch, "fmt ", 4)) {
+            if (len < 16 || len > 65536) throw std::runtime_error("bad fmt chunk");  // (a hostile length is not an allocation)
             std::vector<unsigned char> b(len);
-            if (!r.read(b.data(), len) || len < 16) throw std::runtime_error("bad fmt chunk");
+            if (!r.read(b.data(), len)) throw std::runtime_error("bad fmt chunk");
             fmt_tag = le16(&b[0]);
             channels = le16(&b[2]);
             rate = le32(&b[4]);
@@ -156,14 +157,14 @@ Audio read_wav(FILE *f) {
             if (len & 1) r.skip(1);
         } else if (!memcmp(ch, "data", 4)) {
             if (!have_fmt) throw std::runtime_error("data chunk before fmt chunk");
-            if (len == 0xFFFFFFFFu || len == 0) {  // streamed (stdin) WAV: read to EOF
-                unsigned char buf[65536];
-                size_t k;
-                while ((k = fread(buf, 1, sizeof buf, f)) > 0) raw.insert(raw.end(), buf, buf + k);
-            } else {
-                raw.resize(len);
-                const size_t got = fread(raw.data(), 1, len, f);
-                raw.resize(got);
+            // streamed (stdin) WAV (length 0 or 0xFFFFFFFF): read to EOF; otherwise at most `len` bytes - in pieces, so
+            // that a truncated file with a huge declared length costs the bytes it has, not the bytes it claims
+            const bool to_eof = len == 0xFFFFFFFFu || len == 0;
+            std::vector<unsigned char> buf(1 << 20);
+            size_t left = to_eof ? SIZE_MAX : (size_t)len, k;
+            while (left && (k = fread(buf.data(), 1, std::min(left, buf.size()), f)) > 0) {
+                raw.insert(raw.end(), buf.begin(), buf.begin() + k);
+                left -= k;
             }
             break;
         } else {
@@ -174,7 +175,9 @@ Audio read_wav(FILE *f) {
     (void)block_align;
     const size_t bps = bits / 8;
     if (bps == 0) throw std::runtime_error("unsupported bits per sample");
-    const size_t n = raw.size() / bps;
+    // whole frames only: a file cut inside a frame would leave the channels ragged (the reference de-interleaves by
+    // i % channels, audio_files.rs:39-43, and then indexes every channel up to the first one's length)
+    const size_t n = raw.size() / bps / channels * channels;
     Audio a;
     a.spec.channels = channels;
     a.spec.sample_rate = rate;
@@ -258,7 +261,14 @@ struct WindowQueue {
     // 0 = got item, 1 = timeout, 2 = disconnected
     int recv_timeout(std::vector<float> *out, std::chrono::milliseconds to) {
         std::unique_lock<std::mutex> lk(m);
+#ifdef __SANITIZE_THREAD__
+        // gcc 11's libtsan does not intercept pthread_cond_clockwait (what wait_for on the steady clock calls): it then
+        // believes the mutex stays locked across the wait and reports every access behind it. The system-clock form
+        // goes through pthread_cond_timedwait, which it knows (sanitizer builds only: host/sanitize.mk).
+        if (!cv_item.wait_until(lk, std::chrono::system_clock::now() + to, [&] { return !q.empty() || closed; })) return 1;
+#else
         if (!cv_item.wait_for(lk, to, [&] { return !q.empty() || closed; })) return 1;
+#endif
         if (q.empty()) return 2;
         *out = std::move(q.front());
         q.pop_front();

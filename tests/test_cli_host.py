@@ -10,7 +10,8 @@ import pytest
 from conftest import ROOT
 from wavutil import write_wav
 
-CLI = os.path.join(ROOT, "rocoder_amd", "bin", "rocoder")
+# ROCODER_CLI: run the same tests on another build of the CLI (tools/run_sanitizers.sh: the ASan + UBSan binary)
+CLI = os.environ.get("ROCODER_CLI") or os.path.join(ROOT, "rocoder_amd", "bin", "rocoder")
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -71,3 +72,58 @@ def test_playback_and_recording_are_refused_not_faked(tmp_path):
     write_wav(wav, np.zeros((1, 10)), 8000, "i16")
     assert run("-o", "x.wav").returncode != 0           # no -i: the reference records (cpal)
     assert run("-i", wav).returncode != 0               # no -o: the reference plays (cpal)
+
+
+def _wav_corpus():
+    """Hostile inputs for the WAV reader (it parses untrusted files): every truncation of a valid header, byte
+    flips in the header, absurd chunk lengths, zero / huge channel counts, odd bit depths, chunks in the wrong order."""
+    import io
+    import struct
+
+    rng = np.random.default_rng(11)
+
+    def wav(fmt_tag=1, ch=2, rate=44100, bits=16, data=b"\x01\x02" * 64, fmt_len=16, data_len=None, extra=b"",
+            riff=b"RIFF", wave=b"WAVE", order=("fmt", "data")):
+        fmt = struct.pack("<HHIIHH", fmt_tag, ch, rate, (rate * ch * max(bits, 8) // 8) & 0xFFFFFFFF,
+                          (ch * max(bits, 8) // 8) & 0xFFFF, bits)
+        fmt = (fmt + b"\0" * 64)[:max(fmt_len, 0)] if fmt_len != 16 else fmt
+        chunks = {"fmt": b"fmt " + struct.pack("<I", fmt_len & 0xFFFFFFFF) + fmt,
+                  "data": b"data" + struct.pack("<I", (len(data) if data_len is None else data_len) & 0xFFFFFFFF) + data}
+        body = wave + extra + b"".join(chunks[k] for k in order)
+        return riff + struct.pack("<I", len(body) & 0xFFFFFFFF) + body
+
+    good = wav()
+    corpus = [good[:n] for n in range(0, len(good), 1)][:80]          # every truncation through the header + some data
+    for _ in range(120):                                              # byte flips inside the first 48 bytes
+        b = bytearray(good)
+        for _k in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, 48))] = int(rng.integers(0, 256))
+        corpus.append(bytes(b))
+    corpus += [
+        wav(fmt_len=0xFFFFFFFF), wav(fmt_len=0x7FFFFFF0), wav(fmt_len=15), wav(fmt_len=17), wav(fmt_len=40, fmt_tag=0xFFFE),
+        wav(data_len=0xFFFFFFFE), wav(data_len=0x80000000), wav(data_len=0), wav(data_len=0xFFFFFFFF), wav(data_len=3),
+        wav(ch=0), wav(ch=65535), wav(bits=0), wav(bits=7), wav(bits=12), wav(bits=64), wav(bits=24, data=b"\xff" * 7),
+        wav(fmt_tag=3, bits=16), wav(fmt_tag=3, bits=32, data=b"\x00\x00\xc0\x7f" * 8), wav(fmt_tag=2), wav(rate=0),
+        wav(order=("data", "fmt")), wav(order=("data",)), wav(order=("fmt",)), wav(extra=b"LIST" + struct.pack("<I", 0xFFFFFFFF)),
+        wav(extra=b"junk" + struct.pack("<I", 5) + b"12345\0"), wav(riff=b"RIFX"), wav(wave=b"WAVF"), b"", b"RIFF", good * 2,
+    ]
+    return corpus
+
+
+def test_wav_reader_survives_truncated_and_garbage_files(tmp_path):
+    """No input may crash the reader (a signal) or make it allocate what the file merely claims: it either decodes
+    or fails with a message and a non-zero status - in this build and, through tools/run_sanitizers.sh, under
+    AddressSanitizer + UndefinedBehaviorSanitizer."""
+    corpus = _wav_corpus()
+    assert len(corpus) > 200
+    bad = []
+    for k, blob in enumerate(corpus):
+        wav, raw = str(tmp_path / "f.wav"), str(tmp_path / "f.f32")
+        open(wav, "wb").write(blob)
+        r = run("--decode-wav", wav, raw)
+        if r.returncode < 0 or r.returncode > 1 or "Sanitizer" in r.stderr or "runtime error" in r.stderr:
+            bad.append((k, r.returncode, r.stderr[-300:]))
+        elif r.returncode == 0:  # decoded: the counts it printed are what it wrote
+            ch, _rate, frames = (int(v) for v in r.stdout.split())
+            assert os.path.getsize(raw) == 4 * ch * frames, (k, r.stdout)
+    assert not bad, bad[:5]
