@@ -12,7 +12,7 @@ head -6 $OUT/${TAG}_kernel_stats.csv | cut -c1-200
 i=0
 for CNT in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY" \
-           "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE"; do
+           "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   rocprofv3 --pmc $CNT --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/tools/bench_c5.py > $OUT/pass$i.log 2>&1
 done
@@ -26,6 +26,12 @@ for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
             key = "R64 (N=65536)" if "Li64E" in r["Kernel_Name"] or "<64" in r["Kernel_Name"] else "R32 (N=32768)"
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(f"{out}/{tag}_pmc_summary.txt", "w") as g:
+    try:
+        import json
+        b = json.loads(open(f"{out}/{tag}_bench.json").read())
+        g.write(f"# this box, same call, un-profiled: C5 {b['N65536']['ms_median']} ms, window-32768 twin {b['N32768']['ms_median']} ms ({tag}_bench.json)\n")
+    except Exception as e:  # noqa: BLE001
+        g.write(f"# (no bench line: {e})\n")
     g.write("# big4_kernel, tools/bench_c5.py (8 ch x 5 292 000, factor 32), mean per launch, separate --pmc passes\n")
     for key in sorted(acc):
         g.write(f"## {key}\n")

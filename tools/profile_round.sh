@@ -50,15 +50,17 @@ for CNT in \
   "WRITE_SIZE" \
   "TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
-  rocprofv3 --pmc $CNT --output-format csv -d $OUT/pass$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --preheat-s 0.5 --no-cpu-baseline --no-extras > $OUT/pass$i.log 2>&1
+  # the DEFAULT bench command (same steps, warm-up and pre-heat as the un-profiled line above), minus its CPU legs
+  rocprofv3 --pmc $CNT --output-format csv -d $OUT/pass$i -- python3 $BENCH > $OUT/pass$i.log 2>&1
   echo "pmc pass $i rc=$?"
 done
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, sys, collections, json
 out, tag = sys.argv[1], sys.argv[2]
-kid = "unknown"
+kid, med = "unknown", "?"
 try:
-    kid = json.loads(open(f"{out}/{tag}_bench.json").read().strip().splitlines()[-1])["roofline"]["kernel_id"]
+    roof = json.loads(open(f"{out}/{tag}_bench.json").read().strip().splitlines()[-1])["roofline"]
+    kid, med = roof["kernel_id"], roof["kernel_ms"]
 except Exception as e:  # noqa: BLE001
     print("no kernel id:", e)
 acc = collections.defaultdict(list)
@@ -67,7 +69,9 @@ for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
         if "hop" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(f"{out}/{tag}_pmc_summary.txt", "w") as g:
-    g.write(f"# kernel_id: {kid}\n# mean per hop-kernel launch over all launches of `bench.py --steps 5 --warmup 2 --preheat-s 0.5` (separate --pmc passes)\n")
+    g.write(f"# kernel_id: {kid}\n# this box, same call, un-profiled: kernel median {med} ms ({tag}_bench.json)\n"
+            "# mean per hop-kernel launch over all launches of the DEFAULT bench command (`bench.py --steps 20 --warmup 5 "
+            "--no-cpu-baseline --no-extras`, 2 s pre-heat), separate --pmc passes\n")
     for k in sorted(acc):
         v = acc[k]
         line = f"{k:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}"
