@@ -1079,10 +1079,12 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
         default_window = memcmp(d.data(), w.data(), N * sizeof(float)) == 0;
     }
     std::vector<float> hann_rot;
-    if (default_window && log2n >= 14 && !gen) {
+    if (default_window && log2n >= 5 && !gen) {
         // thread t of the fused kernels touches samples 2 T q + 2 t + e: {cos, sin}(2 pi (2 t + e) / (len - 1)) for
-        // the window (len = N) and the envelope (len = N / 2); T = 256 threads at N = 16384, 512 above
-        const int threads = log2n == 14 ? 256 : 512;
+        // the window (len = N) and the envelope (len = N / 2); T = 256 threads at N = 16384, 512 above, the generic
+        // kernel's geometry below
+        int threads = log2n == 14 ? 256 : 512;
+        if (log2n < 14) rc::hop_geometry(log2n, &threads, nullptr);
         hann_rot.resize((size_t)2 * threads * 4);
         for (int part = 0; part < 2; ++part) {
             const double len1 = (double)((part ? H : N) - 1);

@@ -22,6 +22,7 @@
 //     and the first hop of a run is recomputed (phases are a pure function of (seed,c,k,j)).
 // No MFMA: this is an FFT/SFU/LDS-bound path, not a contraction.
 #include "rc_passes.hpp"
+#include "rc_dit.hpp"  // (the constexpr sine / cosine of the computed-window constants)
 
 namespace rc {
 namespace {
@@ -175,7 +176,34 @@ __device__ __forceinline__ void middle_fused(float2 *lds, int tid, PhaseKey key,
     }
 }
 
-template <int LOG2N, int MODE, bool PITCH1>
+// Default-window fast path (as HANN_W14 / HANN_E14 of the N = 16384 kernels, for every power of two below): thread t
+// touches samples i = 2 T q + 2 t + e, and both windows::hanning (src/windows.rs:4-9) and the crossfade envelope
+// (src/crossfade.rs:4-10) are 0.5 - a cos(2 pi i / (len - 1)) = 0.5 + c[q] cos(beta) + s[q] sin(beta) with
+// beta = 2 pi (2 t + e) / (len - 1) from HopParams::hann_rot (4 + 4 floats per thread and hop) and compile-time c, s:
+// two FMAs per sample pair replace a table load - 5 P loads per hop that were waited on in place.
+template <int LOG2N>
+struct HannG {
+    static constexpr int P = Geo<LOG2N>::P;
+    float wc[P], ws[P], ec[P], es[P];
+};
+template <int LOG2N>
+constexpr HannG<LOG2N> make_hann_g() {
+    using G = Geo<LOG2N>;
+    HannG<LOG2N> k{};
+    for (int q = 0; q < G::P; ++q) {
+        const double aw = 2.0 * CX_PI * (2.0 * G::T * q) / (double)(G::N - 1);
+        k.wc[q] = (float)(-0.5 * cx_cos(aw));
+        k.ws[q] = (float)(0.5 * cx_sin(aw));
+        const double ae = q < G::P / 2 ? 2.0 * CX_PI * (2.0 * G::T * q) / (double)(G::M - 1) : 0.0;
+        k.ec[q] = (float)(-HANN_ENV_AMP * cx_cos(ae));
+        k.es[q] = (float)(HANN_ENV_AMP * cx_sin(ae));
+    }
+    return k;
+}
+template <int LOG2N>
+__device__ constexpr HannG<LOG2N> HANN_G = make_hann_g<LOG2N>();
+
+template <int LOG2N, int MODE, bool PITCH1, bool HANN = false>
 __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(const HopParams p) {
     using G = Geo<LOG2N>;
     constexpr int P = G::P, T = G::T, M = G::M, N = G::N, H = M;
@@ -245,7 +273,33 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
         // src/stretcher.rs:58-59)
         for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
             const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
-            load_hop<LOG2N>(v, p, xc, xt, per_hop(p.window), k, lane2);
+            v2f cbW = {0.f, 0.f}, sbW = cbW, cbE = cbW, sbE = cbW;
+            const v2f half2 = {0.5f, 0.5f};
+            if constexpr (HANN) {  // this thread's {cos, sin}(beta) for the window and the envelope (per hop: L1 hits)
+                int t2 = tid;
+                opaque(t2);
+                GV2 hr = (GV2)per_hop(p.hann_rot) + 2 * t2;
+                const float2 a0 = ldg2(hr), a1 = ldg2(hr + 1), e0 = ldg2(hr + 2 * T), e1 = ldg2(hr + 2 * T + 1);
+                cbW = v2f{a0.x, a1.x};
+                sbW = v2f{a0.y, a1.y};
+                cbE = v2f{e0.x, e1.x};
+                sbE = v2f{e0.y, e1.y};
+                GF src = hop_src(p, xc, xt, k);
+                float xr0[P], xr1[P];
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    xr0[q] = (src + 2 * T * q)[lane2];
+                    xr1[q] = (src + 2 * T * q)[lane2 + 1];
+                }
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    const v2f wq = __builtin_elementwise_fma(v2f{HANN_G<LOG2N>.ws[q], HANN_G<LOG2N>.ws[q]}, sbW,
+                                   __builtin_elementwise_fma(v2f{HANN_G<LOG2N>.wc[q], HANN_G<LOG2N>.wc[q]}, cbW, half2));
+                    v[q] = to_f2(v2f{xr0[q], xr1[q]} * wq);
+                }
+            } else {
+                load_hop<LOG2N>(v, p, xc, xt, per_hop(p.window), k, lane2);
+            }
             st.mark(0);
             forward_passes<G, G::m, 0, true>(v, lds, ctx, wtab, st);
             lds_store<G, LL>(v, lds, ctx.lb[LL]);
@@ -259,7 +313,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
             if (!(RC_ABLATE & 4)) __syncthreads();
             st.mark(15);
             inverse_passes<G, G::m>(v, lds, ctx, wtab, st);
-            {
+            if constexpr (HANN) {
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    const v2f wq = __builtin_elementwise_fma(v2f{HANN_G<LOG2N>.ws[q], HANN_G<LOG2N>.ws[q]}, sbW,
+                                   __builtin_elementwise_fma(v2f{HANN_G<LOG2N>.wc[q], HANN_G<LOG2N>.wc[q]}, cbW, half2));
+                    v[q] = to_f2(to_v(v[q]) * wq);
+                }
+            } else {
                 // window loads for the synthesis multiply: all issued, one wait
                 GF wsrc = per_hop(p.window);
                 float wr0[P], wr1[P];
@@ -282,10 +343,16 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
                     float er0[PH], er1[PH];
 #pragma unroll
                     for (int q = 0; q < PH; ++q) {
-                        er0[q] = (esrc + 2 * T * q)[lane2];
-                        er1[q] = (esrc + 2 * T * q)[lane2 + 1];
+                        if constexpr (HANN) {
+                            const v2f ev = __builtin_elementwise_fma(v2f{HANN_G<LOG2N>.es[q], HANN_G<LOG2N>.es[q]}, sbE,
+                                           __builtin_elementwise_fma(v2f{HANN_G<LOG2N>.ec[q], HANN_G<LOG2N>.ec[q]}, cbE, half2));
+                            er0[q] = ev.x, er1[q] = ev.y;
+                        } else {
+                            er0[q] = (esrc + 2 * T * q)[lane2];
+                            er1[q] = (esrc + 2 * T * q)[lane2 + 1];
+                        }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!HANN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 0; q < PH; ++q) {
                         float2 o;  // stretcher.rs:97-100 operation order
@@ -303,8 +370,16 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
 #pragma unroll
                     for (int q = 0; q < PH; ++q) {
                         const uint32_t i0 = 2u * (uint32_t)(t2 + T * q);
-                        const float o0 = (v[q].x + tail[q].x) * (esrc + 2 * T * q)[lane2] * p.amp;
-                        const float o1 = (v[q].y + tail[q].y) * (esrc + 2 * T * q)[lane2 + 1] * p.amp;
+                        float ex, ey;
+                        if constexpr (HANN) {
+                            const v2f ev = __builtin_elementwise_fma(v2f{HANN_G<LOG2N>.es[q], HANN_G<LOG2N>.es[q]}, sbE,
+                                           __builtin_elementwise_fma(v2f{HANN_G<LOG2N>.ec[q], HANN_G<LOG2N>.ec[q]}, cbE, half2));
+                            ex = ev.x, ey = ev.y;
+                        } else {
+                            ex = (esrc + 2 * T * q)[lane2], ey = (esrc + 2 * T * q)[lane2 + 1];
+                        }
+                        const float o0 = (v[q].x + tail[q].x) * ex * p.amp;
+                        const float o1 = (v[q].y + tail[q].y) * ey * p.amp;
                         const uint32_t a0 = kr + i0, a1 = a0 + 1;
                         const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
                         if (d0 * pitch == a0) dst[d0] = o0;
@@ -333,6 +408,8 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
     switch (mode) {
         case MODE_FUSED:
             if constexpr (LOG2N == 14) return launch_hop16k(p, s);  // hop4_kernel / hop2_kernel (rc_hop16k.hip)
+            else if (p.hann_rot && p.pitch == 1) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true, true>), grid, block, lds, s, p);
+            else if (p.hann_rot) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, false, true>), grid, block, lds, s, p);
             else if (p.pitch == 1) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true>), grid, block, lds, s, p);
             else hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, false>), grid, block, lds, s, p);
             break;

@@ -3,6 +3,9 @@
 #pragma once
 #include "rc_dev.hpp"
 
+#ifndef RC_PASS_SQ
+#define RC_PASS_SQ 1
+#endif
 namespace rc {
 namespace {
 
@@ -33,10 +36,27 @@ __device__ __forceinline__ void run_pass(float2 (&v)[G::P], int tid,
     // being hoisted out of the hop loop into live registers
     float2 bases[S_HI - S_LO + 1];
     if (LOR > 0) {
+        if (RC_PASS_SQ) {
+            // ONE table load per pass (the finest stage's base); the base of stage s - 1 is the square of the base of
+            // stage s (two packed instructions). A global load inside the hop loop is waited on in place and
+            // retires in order behind the previous hop's output stores: five loads per pass were ~20 % of hop2's time
+            float2 bh = ldg2(wtab + (l << (G::m - 1 - S_HI)));
+            opaque(bh);
+            bases[S_HI - S_LO] = bh;
 #pragma unroll
-        for (int si = 0; si <= S_HI - S_LO; ++si) bases[si] = ldg2(wtab + (l << (G::m - 1 - (S_LO + si))));
+            for (int si = S_HI - S_LO - 1; si >= 0; --si) {
+                const v2f a = to_v(bases[si + 1]);
+                const v2f t = __builtin_shufflevector(a, a, 0, 0) * a;
+                v2f sq;  // t + a.yy * (-a.y, a.x) = a * a
+                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(sq) : "v"(a), "v"(a), "v"(t));
+                bases[si] = to_f2(sq);
+            }
+        } else {
 #pragma unroll
-        for (int si = 0; si <= S_HI - S_LO; ++si) opaque(bases[si]);
+            for (int si = 0; si <= S_HI - S_LO; ++si) bases[si] = ldg2(wtab + (l << (G::m - 1 - (S_LO + si))));
+#pragma unroll
+            for (int si = 0; si <= S_HI - S_LO; ++si) opaque(bases[si]);
+        }
     }
 #pragma unroll
     for (int si = 0; si <= S_HI - S_LO; ++si) {
