@@ -99,7 +99,6 @@ template <int LOG2N>
 __device__ __forceinline__ void middle_fused(float2 *lds, int tid, PhaseKey key, GV2 rtab) {
     using G = Geo<LOG2N>;
     constexpr int m = G::m, M = G::M, QN = G::QN;
-    constexpr uint32_t N = 2u * M;
     constexpr int DUMMY = G::LDS_FLOAT2 - 1;
     opaque(tid);
     int ia[QN], ib[QN], ic[QN], id[QN];
@@ -131,8 +130,6 @@ __device__ __forceinline__ void middle_fused(float2 *lds, int tid, PhaseKey key,
     }
     // the two counters of a pair follow from one multiply: x(b) = b*mul + k0 serves bins b and
     // M + b, x(M-b) = (M*mul + 2 k0) - x(b) serves bins M - b and N - b
-    const uint32_t cM = M * key.mul + 2u * key.k0;
-    const float nkappa = -0.25f / (float)N;
 #pragma unroll
     for (int s = 0; s < QN; ++s) {
 #pragma unroll
@@ -143,20 +140,12 @@ __device__ __forceinline__ void middle_fused(float2 *lds, int tid, PhaseKey key,
             const float2 Bp = h ? A2[s] : B2[s];
             const float2 ww = h ? make_float2(-w[s].y, -w[s].x) : w[s];
             const uint32_t jb = h ? (uint32_t)(M / 2) - ja[s] : ja[s];
-            float2 X1, X2c;
-            pair_analyze(A, Bp, ww, X1, X2c);
-            float m1 = cabs_fast(X1) * nkappa, m2 = cabs_fast(X2c) * nkappa;
+            // the pair in packed (re, im) arithmetic (rc_dit.hpp, as the N = 16384 kernels): 17 v_pk_* + 10
+            // transcendental + the two hashes instead of ~50 scalar operations
             const uint32_t x1 = jb * key.mul + key.k0;
-            float c1, s1, c2, s2, c3, s3, c4, s4;
-            phase_ncs2_x(x1, c1, s1, c4, s4);       // bins jb and M + jb
-            phase_ncs2_x(cM - x1, c3, s3, c2, s2);  // bins M - jb and N - jb
-            const float px = m1 * (c1 + c2), py = m1 * (s1 - s2);  // Zs[jb]
-            const float qx = m2 * (c3 + c4), qy = m2 * (s4 - s3);  // conj(Zs[M-jb])
-            const float sx = px + qx, sy = py + qy;
-            const float rx = px - qx, ry = py - qy;
-            const float ux = rx * ww.x + ry * ww.y, uy = ry * ww.x - rx * ww.y;  // U = conj(w) R
-            const float2 VA = make_float2(sx - uy, sy + ux);  // S + iU        -> bin jb
-            const float2 VB = make_float2(sx + uy, ux - sy);  // conj(S - iU)  -> bin M - jb
+            v2f VAv, VBv;
+            pair_regs_pk<LOG2N>(to_v(A), to_v(Bp), to_v(ww), x1, key, VAv, VBv);
+            const float2 VA = to_f2(VAv), VB = to_f2(VBv);
             if (h == 0) {
                 lds[ia[s]] = VA;
                 lds[id[s]] = VB;
@@ -358,7 +347,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
                         float2 o;  // stretcher.rs:97-100 operation order
                         o.x = (v[q].x + tail[q].x) * er0[q] * p.amp;
                         o.y = (v[q].y + tail[q].y) * er1[q] * p.amp;
-                        stg2((GV2W)(dst + 2 * T * q + lane2), o);
+                        // (non-temporal: the output is written once and never read here; the windows of neighbouring
+                        // hops keep the L2)
+                        __builtin_nontemporal_store(to_v(o), (GV2W)(dst + 2 * T * q + lane2));
                     }
                 } else {
                     // F[t] = O[t p]: keep element g = g0 + i iff g % p == 0, at F[g / p]

@@ -37,14 +37,21 @@ __device__ __forceinline__ void run_pass(float2 (&v)[G::P], int tid,
     float2 bases[S_HI - S_LO + 1];
     if (LOR > 0) {
         if (RC_PASS_SQ) {
-            // ONE table load per pass (the finest stage's base); the base of stage s - 1 is the square of the base of
-            // stage s (two packed instructions). A global load inside the hop loop is waited on in place and
-            // retires in order behind the previous hop's output stores: five loads per pass were ~20 % of hop2's time
+            // TWO table loads per pass (the bases of the finest stage and of the one two below it) instead of five; the
+            // others are squares: base(s - 1) = base(s)^2, two packed instructions, at most two deep from a table value
+            // (each squaring doubles the f32 rounding of its input: four deep cost 3e-6 of the output's RMS on the
+            // large-window spectrum path, two deep stays under 1e-6). A global load inside the hop loop is waited on in
+            // place and retires in order behind the previous hop's output stores.
+            constexpr int NS = S_HI - S_LO + 1;
             float2 bh = ldg2(wtab + (l << (G::m - 1 - S_HI)));
+            float2 bm = NS > 2 ? ldg2(wtab + (l << (G::m - 1 - (S_HI - 2)))) : bh;
             opaque(bh);
-            bases[S_HI - S_LO] = bh;
+            opaque(bm);
+            bases[NS - 1] = bh;
+            if (NS > 2) bases[NS - 3] = bm;
 #pragma unroll
-            for (int si = S_HI - S_LO - 1; si >= 0; --si) {
+            for (int si = NS - 2; si >= 0; --si) {
+                if (NS > 2 && si == NS - 3) continue;  // (loaded)
                 const v2f a = to_v(bases[si + 1]);
                 const v2f t = __builtin_shufflevector(a, a, 0, 0) * a;
                 v2f sq;  // t + a.yy * (-a.y, a.x) = a * a
