@@ -237,11 +237,15 @@ struct rc_engine {
     // i, the host apply() calls of chunk i - 1 and the H2D + resynthesis + overlap-add of chunk i - 2
     // overlap (streams kf / kb beside the caller's stream; pinned host buffers)
     struct KernelPipe {
-        DevBuf d_spec[2], d_ybuf[2], d_ysub[2];
-        float *h_in[2] = {nullptr, nullptr}, *h_out[2] = {nullptr, nullptr};
+        // THREE resource sets: with two, the forward transform + D2H of chunk i + 1 had to wait for the set of chunk
+        // i - 1, i.e. for its H2D + resynthesis - the two PCIe directions never ran together. With three, D2H(i + 1)
+        // overlaps H2D(i - 1) (separate copy engines) while the host calls apply() on chunk i.
+        static constexpr int kSets = 3;
+        DevBuf d_spec[kSets], d_ybuf[kSets], d_ysub[kSets];
+        float *h_in[kSets] = {}, *h_out[kSets] = {};
         size_t h_cap = 0;
         hipStream_t kf = nullptr, kb = nullptr;
-        hipEvent_t ev_fwd[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
+        hipEvent_t ev_fwd[kSets] = {}, ev_back[kSets] = {};
         hipEvent_t ev_in = nullptr, ev_done = nullptr;
     } kp;
     // host-buffer calls (rc_engine_stretch_host): pinned staging slots, one per copy worker (host_copy)
@@ -267,8 +271,11 @@ uint64_t now_ms(const rc_engine *e) {
 #ifndef RC_ROUNDS
 #define RC_ROUNDS 2
 #endif
+// independent_hops: the launch is one of the two halves of the spectrum paths (MODE_FORWARD / MODE_RESYNTH): no tail
+// is carried and no hop recomputed, so a run may be a single hop - a chunk of 128 hop indices then fills the chip
+// instead of 32 workgroups walking 8 hops each.
 void plan_runs(const rc_engine *e, uint32_t n_channels, int64_t hop_count, uint32_t *runs,
-               uint32_t *run_len) {
+               uint32_t *run_len, bool independent_hops = false) {
     int threads = 64;
     size_t lds = 0;
     rc::hop_geometry(e->log2n, &threads, &lds);
@@ -291,7 +298,7 @@ void plan_runs(const rc_engine *e, uint32_t n_channels, int64_t hop_count, uint3
 #endif
     const uint64_t target = (uint64_t)e->n_cu * wg_per_cu * rounds;  // rounds of resident workgroups
     uint64_t r = std::max<uint64_t>(1, target / std::max<uint32_t>(1, n_channels));
-    const int64_t min_run = e->tune_min_run > 0 ? e->tune_min_run : 8;
+    const int64_t min_run = independent_hops ? 1 : (e->tune_min_run > 0 ? e->tune_min_run : 8);
     r = std::min<uint64_t>(r, (uint64_t)std::max<int64_t>(1, hop_count / min_run));
     r = std::max<uint64_t>(r, 1);
     uint64_t len = ((uint64_t)hop_count + r - 1) / r;
@@ -380,7 +387,7 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
     if (!kp.kf) {
         RC_HIP(hipStreamCreateWithFlags(&kp.kf, hipStreamNonBlocking));
         RC_HIP(hipStreamCreateWithFlags(&kp.kb, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < rc_engine::KernelPipe::kSets; ++i) {
             RC_HIP(hipEventCreateWithFlags(&kp.ev_fwd[i], hipEventDisableTiming));
             RC_HIP(hipEventCreateWithFlags(&kp.ev_back[i], hipEventDisableTiming));
         }
@@ -388,23 +395,27 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
         RC_HIP(hipEventCreateWithFlags(&kp.ev_done, hipEventDisableTiming));
     }
     const size_t hop_bytes = (size_t)N * 2 * sizeof(float) * n_channels;  // one hop index, all channels
-    int64_t kc_max = (int64_t)(((size_t)32 << 20) / hop_bytes) / hpw * hpw;
+#ifndef RC_KCHUNK_MB
+#define RC_KCHUNK_MB 8  // 32 / 16 / 8 / 4 / 2 MiB measured at C4 (two kernel threads, device-resident job): 28.8 / 27.7 / 24.6 / 28.4 / 35 ms
+#endif
+    int64_t kc_max = (int64_t)(((size_t)RC_KCHUNK_MB << 20) / hop_bytes) / hpw * hpw;
     kc_max = std::max<int64_t>(hpw, std::min<int64_t>(kc_max, (hop_count + hpw - 1) / hpw * hpw));
     const size_t chunk_bytes = (size_t)kc_max * hop_bytes;
-    for (int i = 0; i < 2; ++i) {
+    constexpr int kSets = rc_engine::KernelPipe::kSets;
+    for (int i = 0; i < kSets; ++i) {
         if (int rc = kp.d_spec[i].reserve(chunk_bytes)) return rc;
         if (int rc = kp.d_ybuf[i].reserve(chunk_bytes / 2)) return rc;
         if (big)
             if (int rc = kp.d_ysub[i].reserve(chunk_bytes / 2)) return rc;
     }
     if (kp.h_cap < chunk_bytes) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kSets; ++i) {
             if (kp.h_in[i]) (void)hipHostFree(kp.h_in[i]);
             if (kp.h_out[i]) (void)hipHostFree(kp.h_out[i]);
             kp.h_in[i] = kp.h_out[i] = nullptr;
         }
         kp.h_cap = 0;
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < kSets; ++i) {
             RC_HIP(hipHostMalloc((void **)&kp.h_in[i], chunk_bytes, hipHostMallocDefault));
             RC_HIP(hipHostMalloc((void **)&kp.h_out[i], chunk_bytes, hipHostMallocDefault));
         }
@@ -429,13 +440,13 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
             b->ybuf = q.ybuf;
             b->spec = q.spec;
         } else {
-            plan_runs(e, n_channels, kc, &q.runs_per_channel, &q.run_len);
+            plan_runs(e, n_channels, kc, &q.runs_per_channel, &q.run_len, true);
         }
         return q;
     };
     auto front = [&](int i, int64_t k0, int64_t kc) -> int {  // forward transform + D2H on kf
-        const int set = i & 1;
-        if (i >= 2) RC_HIP(hipStreamWaitEvent(kp.kf, kp.ev_back[set], 0));  // set free again
+        const int set = i % kSets;
+        if (i >= kSets) RC_HIP(hipStreamWaitEvent(kp.kf, kp.ev_back[set], 0));  // set free again
         rc::BigParams b{};
         const rc::HopParams q = params_of(set, k0, kc, &b);
         if (big) {
@@ -452,7 +463,7 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
         return RC_OK;
     };
     auto back = [&](int i, int64_t k0, int64_t kc) -> int {  // apply() here, then H2D .. OLA on kb
-        const int set = i & 1;
+        const int set = i % kSets;
         RC_HIP(hipEventSynchronize(kp.ev_fwd[set]));
         // channels [c0, c1): windows outer, channels inner, hops of a window innermost
         auto apply_range = [&](uint32_t c0, uint32_t c1) {
@@ -784,7 +795,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
             b.ybuf = q.ybuf;
             b.spec = q.spec;
         } else if (!e->gen) {
-            plan_runs(e, n_channels, kc, &q.runs_per_channel, &q.run_len);
+            plan_runs(e, n_channels, kc, &q.runs_per_channel, &q.run_len, true);  // (FORWARD / RESYNTH halves)
         }
 #ifndef RC_BIGCR
 #define RC_BIGCR 1
@@ -1211,7 +1222,7 @@ void rc_engine_destroy(rc_engine *e) {
     e->d_seam_flag.release();
     e->d_run_counter.release();
     e->d_tail_stage.release();
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < rc_engine::KernelPipe::kSets; ++i) {
         e->kp.d_spec[i].release();
         e->kp.d_ybuf[i].release();
         e->kp.d_ysub[i].release();

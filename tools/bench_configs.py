@@ -69,7 +69,24 @@ for threads in (1, 2):
     y = e.stretch_host(xh)
     dt = time.perf_counter() - t0
     res[f"C4_host_callback_{threads}_thread"] = dict(ms=round(dt * 1e3, 1), out_msamples_s=round(y.size / dt / 1e6, 1),
-                                                     note="L=2646000/ch; PCIe both ways + apply() per hop on the host")
+                                                     note="L=2646000/ch; host buffers in AND out (a fresh 169 MB output array "
+                                                          "per call) + the spectra over PCIe both ways + apply() per hop")
+    # the same job with input and output resident in HBM (as for `value`): only the spectra cross PCIe
+    xd = torch.from_numpy(xh).to(dev)
+    outd = torch.empty((2, e.output_len(xd.shape[1])), device=dev)
+    e.stretch_tensor(xd, out=outd)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        e.stretch_tensor(xd, out=outd)
+        torch.cuda.synchronize()
+        e.synchronize()
+        ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[len(ts) // 2]
+    res[f"C4_host_callback_{threads}_thread_device_io"] = dict(ms=round(dt * 1e3, 1), out_msamples_s=round(outd.numel() / dt / 1e6, 1),
+                                                               note="device-resident input and output; median of 5")
+    del xd, outd
     e.close()
 # streaming seam: one channel, chunks of 1 s, windows pulled as they become computable
 import queue  # noqa: E402
