@@ -22,6 +22,9 @@
 //     and the first hop of a run is recomputed (phases are a pure function of (seed,c,k,j)).
 // No MFMA: this is an FFT/SFU/LDS-bound path, not a contraction.
 #include "rc_passes.hpp"
+#ifndef RC_HOPW
+#define RC_HOPW 1  // N = 4096 with the default window runs hopw_kernel (0: the generic kernel, for A/B)
+#endif
 #include "rc_dit.hpp"  // (the constexpr sine / cosine of the computed-window constants)
 
 namespace rc {
@@ -399,6 +402,7 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
     switch (mode) {
         case MODE_FUSED:
             if constexpr (LOG2N == 14) return launch_hop16k(p, s);  // hop4_kernel / hop2_kernel (rc_hop16k.hip)
+            else if (LOG2N == 12 && RC_HOPW && p.hann_rot) return launch_hopw(p, s);  // one wave per hop (rc_hopw.hip)
             else if (p.hann_rot && p.pitch == 1) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true, true>), grid, block, lds, s, p);
             else if (p.hann_rot) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, false, true>), grid, block, lds, s, p);
             else if (p.pitch == 1) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true>), grid, block, lds, s, p);

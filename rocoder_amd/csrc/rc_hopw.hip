@@ -1,0 +1,384 @@
+// N = 4096 with the default hanning window: hopw_kernel - ONE WAVE PER HOP. The M = N/2 = 2048 complex points are
+// 64 lanes x 32 registers, so every one of the four exchanges of hop4_kernel's structure stays inside the wave: no
+// s_barrier at all, the LDS executes a wave's instructions in order and only the compiler needs a fence. hop4's
+// arithmetic otherwise (tests/dev/proto_w.py is the index model: it replays the four exchanges with the address
+// expressions below, checks every hand-over and counts bank conflicts - none):
+//   forward DIT on positions P = brev11(n), passes of (5, 2, 4) stages:
+//     F1  stages 0..4  on the 32 registers (P0..P4; constants only), lane t = low sample bits (coalesced loads),
+//         the analysis window fused into stage 0
+//     F2  stages 5..6  on registers P4..P8, lane = (P0..P3, P9, P10), base twiddle W_128^(P0..P3)
+//     F3  stages 7..10 on two sets of 16 registers (P7..P10): lane tau holds residues tau and 128 - tau, so every
+//         (j, M - j) bin pair sits in one lane and the pair stage runs in registers (lane 0: residues 0 and 64, which
+//         pair with themselves - hop4's re-deal)
+//   inverse DIT on Q = brev11(bin), passes of (4, 2, 5) stages: I1 stages 0..3 on the sets (constants), I2 stages 4..5
+//     on registers Q4..Q8, I3 stages 6..10 on registers Q6..Q10 with lane t = Q0..Q5 (coalesced stores)
+//   exchanges E1..E4: two rounds each over a half-size buffer (1083 float2 per wave); the round is a position bit that
+//     is a register bit on both sides (P4, P6 = the set, Q4 = the set, Q8), so a round is 16 stores + 16 loads per
+//     lane; one weight per position bit and exchange (address = lane part + immediate), conflict-free for the 16-lane
+//     ds_write_b64 groups and the 32-lane ds_read_b64 groups
+// 168 VGPRs and 12 KB of LDS per wave: three waves per SIMD. The first hop of a run is recomputed for its tail (no
+// seam hand-over); a caller-supplied window, pitch != 1 ... all take this kernel except a non-default window (generic).
+#include "rc_dit.hpp"
+
+namespace rc {
+namespace {
+
+constexpr int HW_BUF = 1088;                      // exchange buffer, float2 slots (1083 used)
+constexpr int HW_TA = HW_BUF;                     // [65] W_2048^r, r <= 64
+constexpr int HW_TR = HW_TA + 72;                 // [65] W_4096^r, r <= 64 (r = 64: lane 0's second residue, as i W)
+constexpr int HW_TB = HW_TR + 72;                 // [16] W_128^l
+constexpr int HW_TC = HW_TB + 16;                 // [16] W_64^l
+constexpr int HW_TH = HW_TC + 16;                 // [256] window / envelope rotations: lane t at 2 t (+ 128: envelope)
+constexpr int HOPW_LDS_FLOAT2 = HW_TH + 256;      // 12 160 B
+
+struct HannK32 {
+    float c[32], s[32];
+};
+// value(i) = 0.5 + c[q] cos(beta) + s[q] sin(beta) for sample i = 128 q + 2 t + e, beta = 2 pi (2 t + e) / (len - 1)
+constexpr HannK32 make_hann_w(double amp, int len, int count) {
+    HannK32 k{};
+    for (int q = 0; q < 32; ++q) {
+        const double a = q < count ? 2.0 * CX_PI * 128.0 * q / (double)(len - 1) : 0.0;
+        k.c[q] = (float)(-amp * cx_cos(a));
+        k.s[q] = (float)(amp * cx_sin(a));
+    }
+    return k;
+}
+__device__ constexpr HannK32 HANN_W12 = make_hann_w(0.5, 4096, 32);
+__device__ constexpr HannK32 HANN_E12 = make_hann_w(HANN_ENV_AMP, 2048, 16);
+constexpr double HANN_KAPPA12 = -0.25 / 4096.0;   // -1/(4N): the scale pair_regs_pk4 leaves out (a power of two)
+__device__ constexpr HannK32 HANN_W12K = make_hann_w(0.5 * HANN_KAPPA12, 4096, 32);
+
+// compiler-only ordering of one wave's LDS accesses (no instruction is emitted)
+__device__ __forceinline__ void wfence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool PITCH1>
+__global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
+    constexpr int LOG2N = 12, m = 11, M = 1 << m, H = M, T = 64, P = 32, PH = 16, RES = 128;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int tid = threadIdx.x;
+    const uint32_t run = blockIdx.x % p.runs_per_channel;
+    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
+    int64_t k_end = k_begin + p.run_len;
+    if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
+    if (k_begin >= k_end) return;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
+    const unsigned lane2 = 2u * (unsigned)tid;
+    const uint32_t pitch = PITCH1 ? 1u : p.pitch;
+    {   // tables, once per run
+        GV2 wt = (GV2)p.wtab;  // exp(-2 pi i k / M), k < M / 2
+        GV2 rt = (GV2)p.rtab;  // exp(-2 pi i j / N), j <= M / 4
+        lds[HW_TA + tid] = ldg2(wt + tid);
+        lds[HW_TR + tid] = ldg2(rt + tid);
+        if (tid == 0) {
+            lds[HW_TA + 64] = ldg2(wt + 64);
+            const float2 w64 = ldg2(rt + 64);            // lane 0's second residue: W_N^(64 - 1024) = i W_N^64
+            lds[HW_TR + 64] = make_float2(-w64.y, w64.x);
+        }
+        if (tid < 16) {
+            lds[HW_TB + tid] = ldg2(wt + 16 * tid);
+            lds[HW_TC + tid] = ldg2(wt + 32 * tid);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // hann_rot: [part][lane][4] = {cos, sin}(beta(2t)), {cos, sin}(beta(2t + 1))
+            const float2 a = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid);
+            const float2 b = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid + 1);
+            lds[HW_TH + 128 * i + 2 * tid] = make_float2(a.x, b.x);      // (cos beta_0, cos beta_1)
+            lds[HW_TH + 128 * i + 2 * tid + 1] = make_float2(a.y, b.y);  // (sin beta_0, sin beta_1)
+        }
+        __syncthreads();
+    }
+    // lane identities are re-derived from an opaque copy of the lane id where they are needed (hop4: kept across the hop
+    // they cost ~20 VGPRs and were spilled)
+    auto lane = [&]() {
+        int t = tid;
+        opaque(t);
+        return t;
+    };
+    v2f tail[PH];
+#pragma unroll
+    for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
+    const v2f half2 = {0.5f, 0.5f};
+    const bool is0 = tid == 0;
+
+    for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
+        const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+        v2f v[P];
+        {   // register brev5(q) := z[q * 64 + t] * window ; F1 = stages 0..4
+            GF src = hop_src(p, xc, xt, k);
+            float xr0[P], xr1[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                xr0[q] = (src + 2 * T * q)[lane2];
+                xr1[q] = (src + 2 * T * q)[lane2 + 1];
+            }
+            const v2f cb = to_v(lds[HW_TH + 2 * tid]), sb = to_v(lds[HW_TH + 2 * tid + 1]);
+            // stage 0 pairs registers brev5(q) and brev5(q + 16) = brev5(q) + 1: a +- b with a = x_q w_q and
+            // b = x_{q+16} w_{q+16} is one multiply and two FMAs
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const v2f wl = __builtin_elementwise_fma(v2f{HANN_W12.s[q], HANN_W12.s[q]}, sb,
+                               __builtin_elementwise_fma(v2f{HANN_W12.c[q], HANN_W12.c[q]}, cb, half2));
+                const v2f wh = __builtin_elementwise_fma(v2f{HANN_W12.s[q + 16], HANN_W12.s[q + 16]}, sb,
+                               __builtin_elementwise_fma(v2f{HANN_W12.c[q + 16], HANN_W12.c[q + 16]}, cb, half2));
+                const v2f a = v2f{xr0[q], xr1[q]} * wl, xh = v2f{xr0[q + 16], xr1[q + 16]};
+                v[2 * brev_c(q, 4)] = __builtin_elementwise_fma(xh, wh, a);
+                v[2 * brev_c(q, 4) + 1] = __builtin_elementwise_fma(-xh, wh, a);
+            }
+            dit_stages<32, m, 1, 4, 0, false, false>(v);
+        }
+        // ---- E1: registers P0..P4 -> P4..P8, round = P4. Weights: P0 16, P1 33, P2 66, P3 136, P5 272, P6 544,
+        // P7 1, P8 2, P9 4, P10 8 (lane t: P5 = t5 ... P10 = t0)
+        v2f w2[P];
+        int l2;  // F2 lane identity: (P0..P3) = l2 & 15, P9 = bit 4, P10 = bit 5
+        wfence();
+        {
+            const int t = lane();
+            const int b1s = 272 * ((t >> 5) & 1) + 544 * ((t >> 4) & 1) + ((t >> 3) & 1) + 2 * ((t >> 2) & 1) +
+                            4 * ((t >> 1) & 1) + 8 * (t & 1);
+            l2 = t;
+            const int b1l = 16 * (t & 1) + 33 * ((t >> 1) & 1) + 66 * ((t >> 2) & 1) + 136 * ((t >> 3) & 1) +
+                            4 * ((t >> 4) & 1) + 8 * ((t >> 5) & 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)  // register 16 h + r: (P0..P3) = r
+                    lds[b1s + 16 * (r & 1) + 33 * ((r >> 1) & 1) + 66 * ((r >> 2) & 1) + 136 * ((r >> 3) & 1)] = to_f2(v[16 * h + r]);
+                wfence();
+#pragma unroll
+                for (int sg = 0; sg < 16; ++sg)  // register j = h | sg << 1: (P5, P6, P7, P8) = sg
+                    w2[h | (sg << 1)] = to_v(lds[b1l + 272 * (sg & 1) + 544 * ((sg >> 1) & 1) + ((sg >> 2) & 1) + 2 * ((sg >> 3) & 1)]);
+                wfence();
+            }
+        }
+        dit_stages<32, m, 5, 6, 4, false, true>(w2, to_v(lds[HW_TB + (l2 & 15)]));
+        // ---- E2: registers P4..P8 -> sets of P7..P10, round = P6 = the set. Identity weights on the reduced index
+        v2f va[16], vb[16];
+        wfence();
+        {
+            const int t = lane();
+            const int b2s = (t & 15) + 256 * ((t >> 4) & 1) + 512 * ((t >> 5) & 1);
+            const int tb = (64 - t) & 63;  // low residue bits of 128 - tau (tau = 0: residue 64)
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {  // registers with P6 = 0: (P4, P5, P7, P8) = kk
+                const int j = (kk & 3) | ((kk >> 2) << 3);
+                lds[b2s + 16 * (kk & 1) + 32 * ((kk >> 1) & 1) + 64 * ((kk >> 2) & 1) + 128 * ((kk >> 3) & 1)] = to_f2(w2[j]);
+            }
+            wfence();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) va[q] = to_v(lds[t + 64 * q]);
+            wfence();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const int j = (kk & 3) | 4 | ((kk >> 2) << 3);
+                lds[b2s + 16 * (kk & 1) + 32 * ((kk >> 1) & 1) + 64 * ((kk >> 2) & 1) + 128 * ((kk >> 3) & 1)] = to_f2(w2[j]);
+            }
+            wfence();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) vb[q] = to_v(lds[tb + 64 * q]);
+            wfence();
+        }
+        const int r = lane();  // residue of set A (set B: RES - r; lane 0: RES / 2)
+        {
+            const v2f wa = to_v(lds[HW_TA + r]);    // W_M^r
+            const v2f k16 = {W32_RE[2], W32_IM[2]};
+            v2f wb = vcmul(v2f{wa.x, -wa.y}, k16);  // W_M^(RES - r) = W_16 conj(W_M^r)
+            if (is0) wb = v2f{W32_RE[1], W32_IM[1]};  // lane 0: W_M^64 = W_32
+            dit_stages<16, m, 7, 10, 7, false, true>(va, wa);
+            dit_stages<16, m, 7, 10, 7, false, true>(vb, wb);
+        }
+        // ---- middle stage in registers: pair (A[q], B[15 - q]) = bins (r + 128 q, M - that). Lane 0 owns the two
+        // residues that pair with themselves (0 and 64): its 32 bins form 17 pairs; its registers are re-dealt so that
+        // the same 16 slots compute 16 of them (slots 0..7 on residue 0 with bin 0 as slot 0, slots 8..15 on residue 64
+        // through a second twiddle base / hash counter) and bin 1024 = M / 2 is one extra pair (hop4_kernel)
+        v2f s8 = va[8];
+        {
+            const v2f va0 = va[0];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const v2f a = va[8 + i], b0 = vb[i], b1 = vb[8 + i];
+                const v2f nx = i < 7 ? va[9 + i] : va0;
+                va[8 + i] = vsel(is0, b0, a);
+                vb[i] = vsel(is0, b1, b0);
+                vb[8 + i] = vsel(is0, nx, b1);
+            }
+        }
+        {
+            const float2 wrl = lds[HW_TR + r];
+            const float2 wrh = lds[is0 ? HW_TR + 64 : HW_TR + r];
+            const uint32_t x0 = (uint32_t)r * key.mul + key.k0;
+            const uint32_t dx = (uint32_t)RES * key.mul;
+            const uint32_t x0h = x0 - (is0 ? (uint32_t)(8 * RES - RES / 2) * key.mul : 0u);  // lane 0: bins 64 + 128 (q - 8)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float2 wr = q < 8 ? wrl : wrh;
+                const v2f wrv = to_v(wr);
+                const v2f wq = q == 0 ? wrv : (q == 8 ? v2f{wr.y, -wr.x}
+                               : vcmul(wrv, v2f{W32_RE[q & 15], W32_IM[q & 15]}));  // W_N^(128 q) = W_32^q
+                v2f VA, VB;
+                if (q == 0)
+                    pair_regs_pk4<LOG2N, true>(va[q], vb[15 - q], wq, x0, key, VA, VB, is0);
+                else
+                    pair_regs_pk4<LOG2N>(va[q], vb[15 - q], wq, (q < 8 ? x0 : x0h) + (uint32_t)q * dx, key, VA, VB);
+                va[q] = VA;
+                vb[15 - q] = VB;
+            }
+        }
+        {   // bin M / 2 pairs with itself: exp(-2 pi i (M/2) / N) = -i; then un-deal lane 0's registers
+            v2f V8, V8b;
+            pair_regs_pk4<LOG2N>(s8, s8, v2f{0.0f, -1.0f}, 8u * (uint32_t)RES * key.mul + key.k0, key, V8, V8b);
+            v2f na[8], nb0[8], nb1[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                na[i] = vsel(is0, i == 0 ? V8 : vb[7 + i], va[8 + i]);
+                nb0[i] = vsel(is0, va[8 + i], vb[i]);
+                nb1[i] = vsel(is0, vb[i], vb[8 + i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                va[8 + i] = na[i];
+                vb[i] = nb0[i];
+                vb[8 + i] = nb1[i];
+            }
+        }
+        // ---- inverse: I1 in registers (register index = brev4(q) = Q0..Q3)
+        v2f pa[16], pb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            pa[brev_c(q, 4)] = va[q];
+            pb[brev_c(q, 4)] = vb[q];
+        }
+        dit_stages<16, m, 0, 3, 0, true, false>(pa);
+        dit_stages<16, m, 0, 3, 0, true, false>(pb);
+        // ---- E3: sets of Q0..Q3 -> registers Q4..Q8, round = Q4 = the set. Weights: Q10 1, Q9 2, Q8 4, Q7 8, Q6 16,
+        // Q5 32 (= the residue's low six bits as they stand), Q0 65, Q1 132, Q2 264, Q3 528
+        int l5;  // I2 lane identity: (Q0..Q3) = l5 & 15, Q9 = bit 4, Q10 = bit 5
+        wfence();
+        {
+            const int t = lane();
+            const int tb = (64 - t) & 63;
+            l5 = t;
+            const int b3l = 65 * (t & 1) + 132 * ((t >> 1) & 1) + 264 * ((t >> 2) & 1) + 528 * ((t >> 3) & 1) +
+                            2 * ((t >> 4) & 1) + ((t >> 5) & 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int bs = h ? tb : t;
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    lds[bs + 65 * (q & 1) + 132 * ((q >> 1) & 1) + 264 * ((q >> 2) & 1) + 528 * ((q >> 3) & 1)] = to_f2(h ? pb[q] : pa[q]);
+                wfence();
+#pragma unroll
+                for (int sg = 0; sg < 16; ++sg)  // register k = h | sg << 1: (Q5, Q6, Q7, Q8) = sg
+                    v[h | (sg << 1)] = to_v(lds[b3l + 32 * (sg & 1) + 16 * ((sg >> 1) & 1) + 8 * ((sg >> 2) & 1) + 4 * ((sg >> 3) & 1)]);
+                wfence();
+            }
+        }
+        dit_stages<32, m, 4, 5, 4, true, true>(v, to_v(lds[HW_TC + (l5 & 15)]));
+        // ---- E4: registers Q4..Q8 -> Q6..Q10, round = Q8. Identity weights on the reduced index
+        v2f y[P];
+        wfence();
+        {
+            const int t = lane();
+            const int b4s = (t & 15) + 256 * ((t >> 4) & 1) + 512 * ((t >> 5) & 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk)  // register 16 h + kk: (Q4..Q7) = kk
+                    lds[b4s + 16 * kk] = to_f2(v[16 * h + kk]);
+                wfence();
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {  // register (Q6, Q7, Q9, Q10) = rr, Q8 = h
+                    const int rg = (rr & 3) | (h << 2) | ((rr >> 2) << 3);
+                    y[rg] = to_v(lds[t + 64 * (rr & 1) + 128 * ((rr >> 1) & 1) + 256 * ((rr >> 2) & 1) + 512 * ((rr >> 3) & 1)]);
+                }
+                wfence();
+            }
+        }
+        dit_stages<32, m, 6, 10, 6, true, true>(y, to_v(lds[HW_TA + lane()]));
+
+        // ---- epilogue: synthesis window (times -1/(4N)), overlap-add with the carried tail, store
+        {
+            const int t = lane();
+            const v2f cbW = to_v(lds[HW_TH + 2 * t]), sbW = to_v(lds[HW_TH + 2 * t + 1]);
+            const v2f half2k = {(float)(0.5 * HANN_KAPPA12), (float)(0.5 * HANN_KAPPA12)};
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+                y[q] *= __builtin_elementwise_fma(v2f{HANN_W12K.s[q], HANN_W12K.s[q]}, sbW,
+                        __builtin_elementwise_fma(v2f{HANN_W12K.c[q], HANN_W12K.c[q]}, cbW, half2k));
+            if (k >= k_begin) {
+                const v2f amp2 = {p.amp, p.amp};
+                // env[i] * amp = amp/2 + c_q (amp cb) + s_q (amp sb): the amplitude rides on the per-lane rotation
+                const v2f cbE = to_v(lds[HW_TH + 128 + 2 * t]) * amp2, sbE = to_v(lds[HW_TH + 128 + 2 * t + 1]) * amp2;
+                const v2f halfa = half2 * amp2;
+                const int64_t g0 = k * (int64_t)H;
+                if constexpr (PITCH1) {
+                    const unsigned long long da = (unsigned long long)(outc + (g0 - p.out_origin));
+                    const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);
+                    const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
+                    GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) {
+                        const v2f er = __builtin_elementwise_fma(v2f{HANN_E12.s[q], HANN_E12.s[q]}, sbE,
+                                       __builtin_elementwise_fma(v2f{HANN_E12.c[q], HANN_E12.c[q]}, cbE, halfa));
+                        const v2f o = (y[q] + tail[q]) * er;  // (y + tail) * (env * amp), stretcher.rs:97-100
+                        __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));
+                    }
+                } else {
+                    // F[t] = O[t * pitch] (src/resampler.rs:3-18): branch-free raw buffer stores, a lane that keeps
+                    // nothing stores out of range (hop4_kernel)
+                    const int64_t kq = g0 / pitch;
+                    const uint32_t kr = (uint32_t)(g0 % pitch);
+                    const unsigned long long da = (unsigned long long)(outc + (kq - p.out_origin));
+                    const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);
+                    const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        (void *)(((unsigned long long)dhi << 32) | dlo), 0, 0x40000000, 0x00020000);
+                    constexpr uint32_t DROP = 0xFFFFFFFCu;
+                    const uint32_t a00 = kr + 2u * (uint32_t)t;
+                    const uint32_t d0 = a00 / pitch;
+                    uint32_t rr = a00 - d0 * pitch, d4 = 4u * d0;
+                    const uint32_t qs4 = 4u * ((2u * T) / pitch), rs = (2u * T) - (qs4 / 4u) * pitch;
+#pragma unroll
+                    for (int q = 0; q < PH; ++q) {
+                        const v2f er = __builtin_elementwise_fma(v2f{HANN_E12.s[q], HANN_E12.s[q]}, sbE,
+                                       __builtin_elementwise_fma(v2f{HANN_E12.c[q], HANN_E12.c[q]}, cbE, halfa));
+                        const v2f o = (y[q] + tail[q]) * er;
+                        const float ox = o.x, oy = o.y;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ox), rsrc, rr == 0 ? d4 : DROP, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(oy), rsrc, rr + 1 == pitch ? d4 + 4u : DROP, 0, 0);
+                        d4 += qs4;
+                        rr += rs;
+                        if (rr >= pitch) {
+                            rr -= pitch;
+                            d4 += 4u;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PH; ++q) tail[q] = y[q + PH];
+        }
+    }
+}
+
+}  // namespace
+
+size_t hopw_lds_bytes() { return sizeof(float2) * (size_t)HOPW_LDS_FLOAT2; }
+
+// N = 4096, fused path, default hanning window (HopParams::hann_rot set: [2][64][4]).
+hipError_t launch_hopw(const HopParams &p, hipStream_t s) {
+    const dim3 grid(p.runs_per_channel * p.n_channels), block(64);
+    const size_t lds = sizeof(float2) * (size_t)HOPW_LDS_FLOAT2;
+    if (p.pitch == 1) hipLaunchKernelGGL((hopw_kernel<true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((hopw_kernel<false>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+}  // namespace rc

@@ -155,6 +155,8 @@ hipError_t launch_hop(int log2n, HopMode mode, const HopParams &p, hipStream_t s
 // (between translation units) the N = 16384 fused path: rc_hop16k.hip, and rc_hop16k_prev.hip in the test-hook library
 hipError_t launch_hop16k(const HopParams &p, hipStream_t s);
 hipError_t launch_hop16k_prev(const HopParams &p, hipStream_t s);
+// N = 4096, fused path, default window: one wave per hop (rc_hopw.hip)
+hipError_t launch_hopw(const HopParams &p, hipStream_t s);
 // tail_only: just save y_{last}[H..] of the chunk as the carried tail (no output written)
 hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only = false);
 // stage 0 = A (forward quarter FFTs), 1 = B (radix-4 + middle + radix-4), 2 = C (inverse quarter FFTs)

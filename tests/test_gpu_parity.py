@@ -1062,3 +1062,47 @@ def test_non_power_of_two_window_refft_device_kernel_and_streaming():
     while not s.is_done():
         wins.append(s.next_window().copy())
     assert_parity(np.concatenate(wins), oc.stretch_offline(x[None], N, 4.0, 1.0, 1, seed=8)[0], "streaming 1500")
+
+
+@pytest.mark.parametrize("p", [1, 2, 3])
+def test_4096_wave_per_hop_kernel_every_sample_and_ranges(p):
+    """hopw_kernel (window 4096, default hanning: one wave per hop, every exchange wave-local): a mid-size stereo job
+    on every sample against the oracle (thousands of runs: first-hop recompute at every run start, the end of the
+    stream, lane 0's self-paired bins), per-half-window blocks, and bit-equality of every shard plan with the whole job."""
+    import torch
+
+    ra = _engine_mod()
+    N, f, L, seed = 4096, 8.0, 900_000, 0xABCD
+    x = np.stack([onp.synth_input(c, L) for c in range(2)])
+    xt = torch.from_numpy(x).cuda()
+    with ra.Engine(window_len=N, factor=f, pitch_multiple=p, channels=2, seed=seed) as e:
+        full = e.stretch_tensor(xt)
+        torch.cuda.synchronize()
+        got = full.cpu().numpy()
+        ref = oc.stretch_offline(x, N, f, 1.0, p, seed=seed)
+        assert got.shape == ref.shape
+        for c in range(2):
+            assert_parity(got[c], ref[c], f"hopw p={p} ch{c}")
+        assert_blocks(got, ref, N // 2, f"hopw p={p}")
+        from rocoder_amd.distributed import engine_compute, shard_plan
+
+        wout = e.params.window_out_len
+        nwin = full.shape[1] // wout
+        comp = engine_compute(e, xt)
+        for world in (2, 3, 8):
+            out = torch.zeros_like(full)
+            for s in shard_plan(2, nwin, world):
+                out[s.ch_first:s.ch_first + s.ch_count, s.win_first * wout:(s.win_first + s.win_count) * wout] = comp(s)
+            torch.cuda.synchronize()
+            assert torch.equal(out, full), f"world={world}"
+    # a caller-supplied window that is NOT the default one takes the generic kernel: same oracle
+    w = np.sqrt(oc.hanning(N)).astype(np.float32)
+    with ra.Engine(window_len=N, factor=f, pitch_multiple=p, window=w, seed=seed) as e:
+        got1 = e.stretch_host(x[:1, :60000])[0]
+    st = oc.Stretcher(channels=1, factor=f, pitch_multiple=p, window=w, seed=seed)
+    st.send(x[0, :60000])
+    st.close_input()
+    wins = []
+    while not st.is_done():
+        wins.append(st.next_window())
+    assert_parity(got1, np.concatenate(wins), f"4096 table window p={p}")
