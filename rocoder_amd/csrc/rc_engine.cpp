@@ -271,6 +271,9 @@ uint64_t now_ms(const rc_engine *e) {
 #ifndef RC_ROUNDS
 #define RC_ROUNDS 2
 #endif
+#ifndef RC_ROUNDS_WAVE
+#define RC_ROUNDS_WAVE 2  // the wave-local kernels (tools/ab_rounds.py, ROCODER_AB_N=8192: 1 / 2 / 3 / 4 rounds = 0.741 / 0.733 / 0.751 / 0.752 ms)
+#endif
 // independent_hops: the launch is one of the two halves of the spectrum paths (MODE_FORWARD / MODE_RESYNTH): no tail
 // is carried and no hop recomputed, so a run may be a single hop - a chunk of 128 hop indices then fills the chip
 // instead of 32 workgroups walking 8 hops each.
@@ -291,6 +294,11 @@ void plan_runs(const rc_engine *e, uint32_t n_channels, int64_t hop_count, uint3
         // (tools/ab_rounds.py) 4 / 6 / 8 / 12 rounds = 1.434 / 1.422 / 1.423 / 1.421 ms; shorter runs (min_run 4) lose
         // to the seam hand-overs again
         rounds = 4 * RC_ROUNDS;
+        if (e->tune_rounds > 0) rounds = (uint32_t)e->tune_rounds;
+    }
+    if (const int res = rc::hop_resident_workgroups(e->log2n, e->d_hann_rot != nullptr)) {
+        wg_per_cu = (uint32_t)res;
+        rounds = RC_ROUNDS_WAVE;
         if (e->tune_rounds > 0) rounds = (uint32_t)e->tune_rounds;
     }
 #ifdef RC_WG_PER_CU

@@ -23,7 +23,7 @@
 // No MFMA: this is an FFT/SFU/LDS-bound path, not a contraction.
 #include "rc_passes.hpp"
 #ifndef RC_HOPW
-#define RC_HOPW 1  // N = 4096 with the default window runs hopw_kernel (0: the generic kernel, for A/B)
+#define RC_HOPW 3  // default window: bit 0 N = 4096 runs hopw_kernel, bit 1 N = 8192 runs hopw2_kernel (0: generic, for A/B)
 #endif
 #include "rc_dit.hpp"  // (the constexpr sine / cosine of the computed-window constants)
 
@@ -402,7 +402,8 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
     switch (mode) {
         case MODE_FUSED:
             if constexpr (LOG2N == 14) return launch_hop16k(p, s);  // hop4_kernel / hop2_kernel (rc_hop16k.hip)
-            else if (LOG2N == 12 && RC_HOPW && p.hann_rot) return launch_hopw(p, s);  // one wave per hop (rc_hopw.hip)
+            else if (LOG2N == 12 && (RC_HOPW & 1) && p.hann_rot) return launch_hopw(p, s);  // one wave per hop (rc_hopw.hip)
+            else if (LOG2N == 13 && (RC_HOPW & 2) && p.hann_rot) return launch_hopw2(p, s);  // two waves per hop
             else if (p.hann_rot && p.pitch == 1) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true, true>), grid, block, lds, s, p);
             else if (p.hann_rot) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, false, true>), grid, block, lds, s, p);
             else if (p.pitch == 1) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true>), grid, block, lds, s, p);
@@ -421,6 +422,13 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
 
 int hop_workgroups_per_cu(int log2n, bool default_window) {
     return (log2n == 14 && default_window) ? 3 : 0;  // hop4_kernel: three workgroups per CU
+}
+
+int hop_resident_workgroups(int log2n, bool default_window) {
+    if (!default_window) return 0;
+    if (log2n == 12 && (RC_HOPW & 1)) return 12;  // hopw_kernel: one wave each, three per SIMD
+    if (log2n == 13 && (RC_HOPW & 2)) return 6;   // hopw2_kernel: two waves each
+    return 0;
 }
 
 bool hop_geometry(int log2n, int *threads, size_t *lds_bytes) {

@@ -34,11 +34,11 @@ constexpr int HOPW_LDS_FLOAT2 = HW_TH + 256;      // 12 160 B
 struct HannK32 {
     float c[32], s[32];
 };
-// value(i) = 0.5 + c[q] cos(beta) + s[q] sin(beta) for sample i = 128 q + 2 t + e, beta = 2 pi (2 t + e) / (len - 1)
-constexpr HannK32 make_hann_w(double amp, int len, int count) {
+// value(i) = 0.5 + c[q] cos(beta) + s[q] sin(beta) for sample i = stride q + 2 t + e, beta = 2 pi (2 t + e) / (len - 1)
+constexpr HannK32 make_hann_w(double amp, int len, int count, int stride = 128) {
     HannK32 k{};
     for (int q = 0; q < 32; ++q) {
-        const double a = q < count ? 2.0 * CX_PI * 128.0 * q / (double)(len - 1) : 0.0;
+        const double a = q < count ? 2.0 * CX_PI * (double)stride * q / (double)(len - 1) : 0.0;
         k.c[q] = (float)(-amp * cx_cos(a));
         k.s[q] = (float)(amp * cx_sin(a));
     }
@@ -48,12 +48,181 @@ __device__ constexpr HannK32 HANN_W12 = make_hann_w(0.5, 4096, 32);
 __device__ constexpr HannK32 HANN_E12 = make_hann_w(HANN_ENV_AMP, 2048, 16);
 constexpr double HANN_KAPPA12 = -0.25 / 4096.0;   // -1/(4N): the scale pair_regs_pk4 leaves out (a power of two)
 __device__ constexpr HannK32 HANN_W12K = make_hann_w(0.5 * HANN_KAPPA12, 4096, 32);
+// N = 8192 (hopw2_kernel: 128 threads, sample i = 256 q + 2 t + e)
+__device__ constexpr HannK32 HANN_W13 = make_hann_w(0.5, 8192, 32, 256);
+__device__ constexpr HannK32 HANN_E13 = make_hann_w(HANN_ENV_AMP, 4096, 16, 256);
+constexpr double HANN_KAPPA13 = -0.25 / 8192.0;
+__device__ constexpr HannK32 HANN_W13K = make_hann_w(0.5 * HANN_KAPPA13, 8192, 32, 256);
+
+constexpr int H2_BUF = 2304;                      // hopw2: exchange buffer (2297 used by E1; a wave's own half: 1152)
+constexpr int H2_TA = H2_BUF;                     // [128] W_4096^r
+constexpr int H2_TR = H2_TA + 128;                // [129] W_8192^r, r <= 128 (r = 128: thread 0's second residue, as i W)
+constexpr int H2_TB = H2_TR + 136;                // [16] W_256^l
+constexpr int H2_TC = H2_TB + 16;                 // [16] W_128^l
+constexpr int H2_TH = H2_TC + 16;                 // [512] window / envelope rotations: thread t at 2 t (+ 256: envelope)
+constexpr int HOPW2_LDS_FLOAT2 = H2_TH + 512;     // 24 896 B
 
 // compiler-only ordering of one wave's LDS accesses (no instruction is emitted)
 __device__ __forceinline__ void wfence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     asm volatile("" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
+// ---- pieces shared by the one-wave (N = 4096) and two-wave (N = 8192) kernels -------------------------------------
+// F1: register brev5(q) := z[q * T + t] * window, stages 0..4. Stage 0 pairs registers brev5(q) and brev5(q + 16) =
+// brev5(q) + 1: a +- b with a = x_q w_q and b = x_{q+16} w_{q+16} is one multiply and two FMAs
+template <int T, int m>
+__device__ __forceinline__ void hopw_f1(GF src, unsigned lane2, v2f cb, v2f sb, const HannK32 &W, v2f (&v)[32]) {
+    constexpr int P = 32;
+    const v2f half2 = {0.5f, 0.5f};
+    float xr0[P], xr1[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        xr0[q] = (src + 2 * T * q)[lane2];
+        xr1[q] = (src + 2 * T * q)[lane2 + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const v2f wl = __builtin_elementwise_fma(v2f{W.s[q], W.s[q]}, sb,
+                       __builtin_elementwise_fma(v2f{W.c[q], W.c[q]}, cb, half2));
+        const v2f wh = __builtin_elementwise_fma(v2f{W.s[q + 16], W.s[q + 16]}, sb,
+                       __builtin_elementwise_fma(v2f{W.c[q + 16], W.c[q + 16]}, cb, half2));
+        const v2f a = v2f{xr0[q], xr1[q]} * wl, xh = v2f{xr0[q + 16], xr1[q + 16]};
+        v[2 * brev_c(q, 4)] = __builtin_elementwise_fma(xh, wh, a);
+        v[2 * brev_c(q, 4) + 1] = __builtin_elementwise_fma(-xh, wh, a);
+    }
+    dit_stages<32, m, 1, 4, 0, false, false>(v);
+}
+
+// The middle stage in registers: pair (A[q], B[15 - q]) = bins (r + RES q, M - that), M = 16 RES. Thread 0 owns the
+// two residues that pair with themselves (0 and RES / 2): its 32 bins form 17 pairs; its registers are re-dealt so that
+// the same 16 slots compute 16 of them (slots 0..7 on residue 0 with bin 0 as slot 0, slots 8..15 on residue RES / 2
+// through a second twiddle base wrh / hash counter) and bin M / 2 is one extra pair (hop4_kernel).
+// wrl = W_N^r, wrh = the same (thread 0: i W_N^(RES / 2)); W_N^(RES q) = W_32^q at both sizes.
+template <int LOG2N, int RES>
+__device__ __forceinline__ void hopw_middle(v2f (&va)[16], v2f (&vb)[16], const bool is0, const uint32_t r,
+                                            const float2 wrl, const float2 wrh, const PhaseKey &key) {
+    static_assert((1 << LOG2N) == 32 * RES, "N = 32 RES");
+    v2f s8 = va[8];
+    {
+        const v2f va0 = va[0];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const v2f a = va[8 + i], b0 = vb[i], b1 = vb[8 + i];
+            const v2f nx = i < 7 ? va[9 + i] : va0;
+            va[8 + i] = vsel(is0, b0, a);
+            vb[i] = vsel(is0, b1, b0);
+            vb[8 + i] = vsel(is0, nx, b1);
+        }
+    }
+    {
+        const uint32_t x0 = r * key.mul + key.k0;
+        const uint32_t dx = (uint32_t)RES * key.mul;
+        const uint32_t x0h = x0 - (is0 ? (uint32_t)(8 * RES - RES / 2) * key.mul : 0u);  // thread 0: bins RES/2 + RES (q - 8)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float2 wr = q < 8 ? wrl : wrh;
+            const v2f wrv = to_v(wr);
+            const v2f wq = q == 0 ? wrv : (q == 8 ? v2f{wr.y, -wr.x}
+                           : vcmul(wrv, v2f{W32_RE[q & 15], W32_IM[q & 15]}));  // W_N^(RES q) = W_32^q
+            v2f VA, VB;
+            if (q == 0)
+                pair_regs_pk4<LOG2N, true>(va[q], vb[15 - q], wq, x0, key, VA, VB, is0);
+            else
+                pair_regs_pk4<LOG2N>(va[q], vb[15 - q], wq, (q < 8 ? x0 : x0h) + (uint32_t)q * dx, key, VA, VB);
+            va[q] = VA;
+            vb[15 - q] = VB;
+        }
+    }
+    {   // bin M / 2 pairs with itself: exp(-2 pi i (M/2) / N) = -i; then un-deal thread 0's registers
+        v2f V8, V8b;
+        pair_regs_pk4<LOG2N>(s8, s8, v2f{0.0f, -1.0f}, 8u * (uint32_t)RES * key.mul + key.k0, key, V8, V8b);
+        v2f na[8], nb0[8], nb1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            na[i] = vsel(is0, i == 0 ? V8 : vb[7 + i], va[8 + i]);
+            nb0[i] = vsel(is0, va[8 + i], vb[i]);
+            nb1[i] = vsel(is0, vb[i], vb[8 + i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            va[8 + i] = na[i];
+            vb[i] = nb0[i];
+            vb[8 + i] = nb1[i];
+        }
+    }
+}
+
+// Epilogue: synthesis window (times -1/(4N)), overlap-add with the carried tail, store. cbW.. = this thread's window /
+// envelope rotations (cos, sin of beta(2 t), beta(2 t + 1)); t = the thread's index in the hop, 2 T samples per row
+template <bool PITCH1, int T>
+__device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, const int64_t k, const bool emit, const int t,
+                                              v2f (&y)[32], v2f (&tail)[16], const v2f cbW, const v2f sbW, v2f cbE,
+                                              v2f sbE, const HannK32 &WK, const HannK32 &E, const float half_kappa,
+                                              const uint32_t pitch) {
+    constexpr int P = 32, PH = 16, H = T * P;
+    const v2f half2 = {0.5f, 0.5f};
+    const unsigned lane2 = 2u * (unsigned)t;
+    const v2f half2k = {half_kappa, half_kappa};
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+        y[q] *= __builtin_elementwise_fma(v2f{WK.s[q], WK.s[q]}, sbW,
+                __builtin_elementwise_fma(v2f{WK.c[q], WK.c[q]}, cbW, half2k));
+    if (emit) {
+        const v2f amp2 = {p.amp, p.amp};
+        // env[i] * amp = amp/2 + c_q (amp cb) + s_q (amp sb): the amplitude rides on the per-thread rotation
+        cbE *= amp2;
+        sbE *= amp2;
+        const v2f halfa = half2 * amp2;
+        const int64_t g0 = k * (int64_t)H;
+        if constexpr (PITCH1) {
+            const unsigned long long da = (unsigned long long)(outc + (g0 - p.out_origin));
+            const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);
+            const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
+            GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
+#pragma unroll
+            for (int q = 0; q < PH; ++q) {
+                const v2f er = __builtin_elementwise_fma(v2f{E.s[q], E.s[q]}, sbE,
+                               __builtin_elementwise_fma(v2f{E.c[q], E.c[q]}, cbE, halfa));
+                const v2f o = (y[q] + tail[q]) * er;  // (y + tail) * (env * amp), stretcher.rs:97-100
+                __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));
+            }
+        } else {
+            // F[t] = O[t * pitch] (src/resampler.rs:3-18): branch-free raw buffer stores, a lane that keeps
+            // nothing stores out of range (hop4_kernel)
+            const int64_t kq = g0 / pitch;
+            const uint32_t kr = (uint32_t)(g0 % pitch);
+            const unsigned long long da = (unsigned long long)(outc + (kq - p.out_origin));
+            const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);
+            const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(((unsigned long long)dhi << 32) | dlo), 0, 0x40000000, 0x00020000);
+            constexpr uint32_t DROP = 0xFFFFFFFCu;
+            const uint32_t a00 = kr + 2u * (uint32_t)t;
+            const uint32_t d0 = a00 / pitch;
+            uint32_t rr = a00 - d0 * pitch, d4 = 4u * d0;
+            const uint32_t qs4 = 4u * ((2u * T) / pitch), rs = (2u * T) - (qs4 / 4u) * pitch;
+#pragma unroll
+            for (int q = 0; q < PH; ++q) {
+                const v2f er = __builtin_elementwise_fma(v2f{E.s[q], E.s[q]}, sbE,
+                               __builtin_elementwise_fma(v2f{E.c[q], E.c[q]}, cbE, halfa));
+                const v2f o = (y[q] + tail[q]) * er;
+                const float ox = o.x, oy = o.y;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ox), rsrc, rr == 0 ? d4 : DROP, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(oy), rsrc, rr + 1 == pitch ? d4 + 4u : DROP, 0, 0);
+                d4 += qs4;
+                rr += rs;
+                if (rr >= pitch) {
+                    rr -= pitch;
+                    d4 += 4u;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PH; ++q) tail[q] = y[q + PH];
 }
 
 template <bool PITCH1>
@@ -105,35 +274,12 @@ __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
     v2f tail[PH];
 #pragma unroll
     for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
-    const v2f half2 = {0.5f, 0.5f};
     const bool is0 = tid == 0;
 
     for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         v2f v[P];
-        {   // register brev5(q) := z[q * 64 + t] * window ; F1 = stages 0..4
-            GF src = hop_src(p, xc, xt, k);
-            float xr0[P], xr1[P];
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                xr0[q] = (src + 2 * T * q)[lane2];
-                xr1[q] = (src + 2 * T * q)[lane2 + 1];
-            }
-            const v2f cb = to_v(lds[HW_TH + 2 * tid]), sb = to_v(lds[HW_TH + 2 * tid + 1]);
-            // stage 0 pairs registers brev5(q) and brev5(q + 16) = brev5(q) + 1: a +- b with a = x_q w_q and
-            // b = x_{q+16} w_{q+16} is one multiply and two FMAs
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const v2f wl = __builtin_elementwise_fma(v2f{HANN_W12.s[q], HANN_W12.s[q]}, sb,
-                               __builtin_elementwise_fma(v2f{HANN_W12.c[q], HANN_W12.c[q]}, cb, half2));
-                const v2f wh = __builtin_elementwise_fma(v2f{HANN_W12.s[q + 16], HANN_W12.s[q + 16]}, sb,
-                               __builtin_elementwise_fma(v2f{HANN_W12.c[q + 16], HANN_W12.c[q + 16]}, cb, half2));
-                const v2f a = v2f{xr0[q], xr1[q]} * wl, xh = v2f{xr0[q + 16], xr1[q + 16]};
-                v[2 * brev_c(q, 4)] = __builtin_elementwise_fma(xh, wh, a);
-                v[2 * brev_c(q, 4) + 1] = __builtin_elementwise_fma(-xh, wh, a);
-            }
-            dit_stages<32, m, 1, 4, 0, false, false>(v);
-        }
+        hopw_f1<T, m>(hop_src(p, xc, xt, k), lane2, to_v(lds[HW_TH + 2 * tid]), to_v(lds[HW_TH + 2 * tid + 1]), HANN_W12, v);
         // ---- E1: registers P0..P4 -> P4..P8, round = P4. Weights: P0 16, P1 33, P2 66, P3 136, P5 272, P6 544,
         // P7 1, P8 2, P9 4, P10 8 (lane t: P5 = t5 ... P10 = t0)
         v2f w2[P];
@@ -194,60 +340,8 @@ __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
             dit_stages<16, m, 7, 10, 7, false, true>(va, wa);
             dit_stages<16, m, 7, 10, 7, false, true>(vb, wb);
         }
-        // ---- middle stage in registers: pair (A[q], B[15 - q]) = bins (r + 128 q, M - that). Lane 0 owns the two
-        // residues that pair with themselves (0 and 64): its 32 bins form 17 pairs; its registers are re-dealt so that
-        // the same 16 slots compute 16 of them (slots 0..7 on residue 0 with bin 0 as slot 0, slots 8..15 on residue 64
-        // through a second twiddle base / hash counter) and bin 1024 = M / 2 is one extra pair (hop4_kernel)
-        v2f s8 = va[8];
-        {
-            const v2f va0 = va[0];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const v2f a = va[8 + i], b0 = vb[i], b1 = vb[8 + i];
-                const v2f nx = i < 7 ? va[9 + i] : va0;
-                va[8 + i] = vsel(is0, b0, a);
-                vb[i] = vsel(is0, b1, b0);
-                vb[8 + i] = vsel(is0, nx, b1);
-            }
-        }
-        {
-            const float2 wrl = lds[HW_TR + r];
-            const float2 wrh = lds[is0 ? HW_TR + 64 : HW_TR + r];
-            const uint32_t x0 = (uint32_t)r * key.mul + key.k0;
-            const uint32_t dx = (uint32_t)RES * key.mul;
-            const uint32_t x0h = x0 - (is0 ? (uint32_t)(8 * RES - RES / 2) * key.mul : 0u);  // lane 0: bins 64 + 128 (q - 8)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float2 wr = q < 8 ? wrl : wrh;
-                const v2f wrv = to_v(wr);
-                const v2f wq = q == 0 ? wrv : (q == 8 ? v2f{wr.y, -wr.x}
-                               : vcmul(wrv, v2f{W32_RE[q & 15], W32_IM[q & 15]}));  // W_N^(128 q) = W_32^q
-                v2f VA, VB;
-                if (q == 0)
-                    pair_regs_pk4<LOG2N, true>(va[q], vb[15 - q], wq, x0, key, VA, VB, is0);
-                else
-                    pair_regs_pk4<LOG2N>(va[q], vb[15 - q], wq, (q < 8 ? x0 : x0h) + (uint32_t)q * dx, key, VA, VB);
-                va[q] = VA;
-                vb[15 - q] = VB;
-            }
-        }
-        {   // bin M / 2 pairs with itself: exp(-2 pi i (M/2) / N) = -i; then un-deal lane 0's registers
-            v2f V8, V8b;
-            pair_regs_pk4<LOG2N>(s8, s8, v2f{0.0f, -1.0f}, 8u * (uint32_t)RES * key.mul + key.k0, key, V8, V8b);
-            v2f na[8], nb0[8], nb1[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                na[i] = vsel(is0, i == 0 ? V8 : vb[7 + i], va[8 + i]);
-                nb0[i] = vsel(is0, va[8 + i], vb[i]);
-                nb1[i] = vsel(is0, vb[i], vb[8 + i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                va[8 + i] = na[i];
-                vb[i] = nb0[i];
-                vb[8 + i] = nb1[i];
-            }
-        }
+        // ---- middle stage in registers (hopw_middle)
+        hopw_middle<LOG2N, RES>(va, vb, is0, (uint32_t)r, lds[HW_TR + r], lds[is0 ? HW_TR + 64 : HW_TR + r], key);
         // ---- inverse: I1 in registers (register index = brev4(q) = Q0..Q3)
         v2f pa[16], pb[16];
 #pragma unroll
@@ -303,67 +397,208 @@ __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
         }
         dit_stages<32, m, 6, 10, 6, true, true>(y, to_v(lds[HW_TA + lane()]));
 
-        // ---- epilogue: synthesis window (times -1/(4N)), overlap-add with the carried tail, store
         {
             const int t = lane();
-            const v2f cbW = to_v(lds[HW_TH + 2 * t]), sbW = to_v(lds[HW_TH + 2 * t + 1]);
-            const v2f half2k = {(float)(0.5 * HANN_KAPPA12), (float)(0.5 * HANN_KAPPA12)};
+            hopw_epilogue<PITCH1, T>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[HW_TH + 2 * t]), to_v(lds[HW_TH + 2 * t + 1]),
+                                     to_v(lds[HW_TH + 128 + 2 * t]), to_v(lds[HW_TH + 128 + 2 * t + 1]), HANN_W12K, HANN_E12,
+                                     (float)(0.5 * HANN_KAPPA12), pitch);
+        }
+    }
+}
+
+
+// ---- N = 8192: hopw2_kernel - TWO WAVES PER HOP (128 threads x 32 complex points, M = 4096) ---------------------
+// hopw_kernel's structure with one more stage (passes of (5, 3, 4) / (4, 3, 5)); tests/dev/proto_w2.py is the index
+// model. The wave is the LOWEST position bit P0 = lowest bin bit = Q11 wherever the data is in bin order: residue r and
+// its partner 256 - r have the same parity, so both bins of a pair, F2 before and I2 after, live in one wave and the
+// exchanges E2 / E3 are wave-local (each wave in its own half of the buffer, no barrier). E1 (sample order -> P0 waves)
+// and E4 (back) cross the two waves: a workgroup barrier around each of their rounds, 9 per hop, between two waves only.
+//   F1 stages 0..4 (thread t = low sample bits: lane = P11..P6, wave = P5), F2 stages 5..7 on registers P4..P8
+//   (lane = P1..P3, P9..P11), F3 stages 8..11 on two sets of 16 (thread tau = 2 lane + wave holds residues tau and
+//   256 - tau; thread 0: residues 0 and 128); I1 stages 0..3, I2 stages 4..6 on registers Q4..Q8, I3 stages 7..11 on
+//   registers Q7..Q11 (thread = Q0..Q6).
+template <bool PITCH1>
+__global__ __launch_bounds__(128, 3) void hopw2_kernel(const HopParams p) {
+    constexpr int LOG2N = 13, m = 12, T = 128, P = 32, PH = 16, RES = 256, HALF = H2_BUF / 2;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int tid = threadIdx.x;
+    const uint32_t run = blockIdx.x % p.runs_per_channel;
+    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
+    int64_t k_end = k_begin + p.run_len;
+    if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
+    if (k_begin >= k_end) return;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
+    const unsigned lane2 = 2u * (unsigned)tid;
+    const uint32_t pitch = PITCH1 ? 1u : p.pitch;
+    {   // tables, once per run
+        GV2 wt = (GV2)p.wtab;  // exp(-2 pi i k / M), k < M / 2
+        GV2 rt = (GV2)p.rtab;  // exp(-2 pi i j / N), j <= M / 4
+        lds[H2_TA + tid] = ldg2(wt + tid);
+        lds[H2_TR + tid] = ldg2(rt + tid);
+        if (tid == 0) {
+            const float2 wh = ldg2(rt + 128);             // thread 0's second residue: W_N^(128 - 2048) = i W_N^128
+            lds[H2_TR + 128] = make_float2(-wh.y, wh.x);
+        }
+        if (tid < 16) {
+            lds[H2_TB + tid] = ldg2(wt + 16 * tid);       // W_256^l
+            lds[H2_TC + tid] = ldg2(wt + 32 * tid);       // W_128^l
+        }
 #pragma unroll
-            for (int q = 0; q < P; ++q)
-                y[q] *= __builtin_elementwise_fma(v2f{HANN_W12K.s[q], HANN_W12K.s[q]}, sbW,
-                        __builtin_elementwise_fma(v2f{HANN_W12K.c[q], HANN_W12K.c[q]}, cbW, half2k));
-            if (k >= k_begin) {
-                const v2f amp2 = {p.amp, p.amp};
-                // env[i] * amp = amp/2 + c_q (amp cb) + s_q (amp sb): the amplitude rides on the per-lane rotation
-                const v2f cbE = to_v(lds[HW_TH + 128 + 2 * t]) * amp2, sbE = to_v(lds[HW_TH + 128 + 2 * t + 1]) * amp2;
-                const v2f halfa = half2 * amp2;
-                const int64_t g0 = k * (int64_t)H;
-                if constexpr (PITCH1) {
-                    const unsigned long long da = (unsigned long long)(outc + (g0 - p.out_origin));
-                    const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);
-                    const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
-                    GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
+        for (int i = 0; i < 2; ++i) {  // hann_rot: [part][thread][4] = {cos, sin}(beta(2t)), {cos, sin}(beta(2t + 1))
+            const float2 a = ldg2((GV2)p.hann_rot + 256 * i + 2 * tid);
+            const float2 b = ldg2((GV2)p.hann_rot + 256 * i + 2 * tid + 1);
+            lds[H2_TH + 256 * i + 2 * tid] = make_float2(a.x, b.x);      // (cos beta_0, cos beta_1)
+            lds[H2_TH + 256 * i + 2 * tid + 1] = make_float2(a.y, b.y);  // (sin beta_0, sin beta_1)
+        }
+        __syncthreads();
+    }
+    auto thread = [&]() {  // (an opaque copy: identities derived from it are not kept live across the hop)
+        int t = tid;
+        opaque(t);
+        return t;
+    };
+    v2f tail[PH];
 #pragma unroll
-                    for (int q = 0; q < PH; ++q) {
-                        const v2f er = __builtin_elementwise_fma(v2f{HANN_E12.s[q], HANN_E12.s[q]}, sbE,
-                                       __builtin_elementwise_fma(v2f{HANN_E12.c[q], HANN_E12.c[q]}, cbE, halfa));
-                        const v2f o = (y[q] + tail[q]) * er;  // (y + tail) * (env * amp), stretcher.rs:97-100
-                        __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));
-                    }
-                } else {
-                    // F[t] = O[t * pitch] (src/resampler.rs:3-18): branch-free raw buffer stores, a lane that keeps
-                    // nothing stores out of range (hop4_kernel)
-                    const int64_t kq = g0 / pitch;
-                    const uint32_t kr = (uint32_t)(g0 % pitch);
-                    const unsigned long long da = (unsigned long long)(outc + (kq - p.out_origin));
-                    const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);
-                    const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
-                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                        (void *)(((unsigned long long)dhi << 32) | dlo), 0, 0x40000000, 0x00020000);
-                    constexpr uint32_t DROP = 0xFFFFFFFCu;
-                    const uint32_t a00 = kr + 2u * (uint32_t)t;
-                    const uint32_t d0 = a00 / pitch;
-                    uint32_t rr = a00 - d0 * pitch, d4 = 4u * d0;
-                    const uint32_t qs4 = 4u * ((2u * T) / pitch), rs = (2u * T) - (qs4 / 4u) * pitch;
+    for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
+    const bool is0 = tid == 0;
+
+    for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
+        const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+        v2f v[P];
+        hopw_f1<T, m>(hop_src(p, xc, xt, k), lane2, to_v(lds[H2_TH + 2 * tid]), to_v(lds[H2_TH + 2 * tid + 1]), HANN_W13, v);
+        // ---- E1 (cross-wave): registers P0..P4 -> P4..P8, round = P4. Weights: P8 1, P9 2, P10 4, P11 8, P1 16, P2 33,
+        // P3 72, P0 144, P5 288, P6 576, P7 1152 (writer: wave = P5, lane: P6 = bit 5 ... P11 = bit 0)
+        v2f w2[P];
+        int l2, wv;  // F2 identity: wave = P0, lane bits (P1, P2, P3, P9, P10, P11)
+        {
+            const int t = thread();
+            const int ln = t & 63;
+            wv = t >> 6;
+            l2 = ln;
+            const int b1s = 288 * wv + 576 * ((ln >> 5) & 1) + 1152 * ((ln >> 4) & 1) + ((ln >> 3) & 1) +
+                            2 * ((ln >> 2) & 1) + 4 * ((ln >> 1) & 1) + 8 * (ln & 1);
+            const int b1l = 144 * wv + 16 * (ln & 1) + 33 * ((ln >> 1) & 1) + 72 * ((ln >> 2) & 1) +
+                            2 * ((ln >> 3) & 1) + 4 * ((ln >> 4) & 1) + 8 * ((ln >> 5) & 1);
 #pragma unroll
-                    for (int q = 0; q < PH; ++q) {
-                        const v2f er = __builtin_elementwise_fma(v2f{HANN_E12.s[q], HANN_E12.s[q]}, sbE,
-                                       __builtin_elementwise_fma(v2f{HANN_E12.c[q], HANN_E12.c[q]}, cbE, halfa));
-                        const v2f o = (y[q] + tail[q]) * er;
-                        const float ox = o.x, oy = o.y;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ox), rsrc, rr == 0 ? d4 : DROP, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(oy), rsrc, rr + 1 == pitch ? d4 + 4u : DROP, 0, 0);
-                        d4 += qs4;
-                        rr += rs;
-                        if (rr >= pitch) {
-                            rr -= pitch;
-                            d4 += 4u;
-                        }
-                    }
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)  // register 16 h + r: (P0..P3) = r
+                    lds[b1s + 144 * (r & 1) + 16 * ((r >> 1) & 1) + 33 * ((r >> 2) & 1) + 72 * ((r >> 3) & 1)] = to_f2(v[16 * h + r]);
+                __syncthreads();
+#pragma unroll
+                for (int sg = 0; sg < 16; ++sg)  // register j = h | sg << 1: (P5, P6, P7, P8) = sg
+                    w2[h | (sg << 1)] = to_v(lds[b1l + 288 * (sg & 1) + 576 * ((sg >> 1) & 1) + 1152 * ((sg >> 2) & 1) + ((sg >> 3) & 1)]);
+                __syncthreads();
+            }
+        }
+        dit_stages<32, m, 5, 7, 4, false, true>(w2, to_v(lds[H2_TB + wv + 2 * (l2 & 7)]));
+        // ---- E2 (wave-local, own half): registers P4..P8 -> sets of P8..P11, round = P7 = the set. Weights: P1 1, P2 2,
+        // P3 4, P4 8, P5 16, P6 32, P8 64, P9 136, P10 264, P11 528
+        v2f va[16], vb[16];
+        wfence();
+        {
+            const int t = thread();
+            const int ln = t & 63, w = t >> 6;
+            float2 *own = lds + HALF * w;
+            const int b2s = (ln & 7) + 136 * ((ln >> 3) & 1) + 264 * ((ln >> 4) & 1) + 528 * ((ln >> 5) & 1);
+            const int tb = (64 - ln - w) & 63;  // bits 1..6 of residue 256 - tau (tau = 0: residue 128)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {  // registers with P7 = h: (P4, P5, P6, P8) = kk
+                    const int j = (kk & 7) | (h << 3) | ((kk >> 3) << 4);
+                    own[b2s + 8 * (kk & 1) + 16 * ((kk >> 1) & 1) + 32 * ((kk >> 2) & 1) + 64 * ((kk >> 3) & 1)] = to_f2(w2[j]);
+                }
+                wfence();
+                const int bl = h ? tb : ln;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const v2f x = to_v(own[bl + 64 * (q & 1) + 136 * ((q >> 1) & 1) + 264 * ((q >> 2) & 1) + 528 * ((q >> 3) & 1)]);
+                    if (h) vb[q] = x;
+                    else va[q] = x;
+                }
+                wfence();
+            }
+        }
+        const int r = [&]() {  // residue of set A: tau = 2 lane + wave (set B: RES - tau; thread 0: RES / 2)
+            const int t = thread();
+            return 2 * (t & 63) + (t >> 6);
+        }();
+        {
+            const v2f wa = to_v(lds[H2_TA + r]);    // W_M^r
+            const v2f k16 = {W32_RE[2], W32_IM[2]};
+            v2f wb = vcmul(v2f{wa.x, -wa.y}, k16);  // W_M^(RES - r) = W_16 conj(W_M^r)
+            if (is0) wb = v2f{W32_RE[1], W32_IM[1]};  // thread 0: W_M^128 = W_32
+            dit_stages<16, m, 8, 11, 8, false, true>(va, wa);
+            dit_stages<16, m, 8, 11, 8, false, true>(vb, wb);
+        }
+        hopw_middle<LOG2N, RES>(va, vb, is0, (uint32_t)r, lds[H2_TR + r], lds[is0 ? H2_TR + 128 : H2_TR + r], key);
+        // ---- inverse: I1 in registers (register index = brev4(q) = Q0..Q3)
+        v2f pa[16], pb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            pa[brev_c(q, 4)] = va[q];
+            pb[brev_c(q, 4)] = vb[q];
+        }
+        dit_stages<16, m, 0, 3, 0, true, false>(pa);
+        dit_stages<16, m, 0, 3, 0, true, false>(pb);
+        // ---- E3 (wave-local): sets of Q0..Q3 -> registers Q4..Q8, round = Q4 = the set. Weights: Q10 1, Q9 2, Q8 4,
+        // Q7 8, Q6 16, Q5 32 (= bits 1..6 of the residue as they stand), Q0 65, Q1 132, Q2 264, Q3 528
+        int l5;  // I2 identity: wave = Q11, lane bits (Q0..Q3, Q9, Q10)
+        wfence();
+        {
+            const int t = thread();
+            const int ln = t & 63, w = t >> 6;
+            float2 *own = lds + HALF * w;
+            const int tb = (64 - ln - w) & 63;
+            l5 = ln;
+            const int b3l = 65 * (ln & 1) + 132 * ((ln >> 1) & 1) + 264 * ((ln >> 2) & 1) + 528 * ((ln >> 3) & 1) +
+                            2 * ((ln >> 4) & 1) + ((ln >> 5) & 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int bs = h ? tb : ln;
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    own[bs + 65 * (q & 1) + 132 * ((q >> 1) & 1) + 264 * ((q >> 2) & 1) + 528 * ((q >> 3) & 1)] = to_f2(h ? pb[q] : pa[q]);
+                wfence();
+#pragma unroll
+                for (int sg = 0; sg < 16; ++sg)  // register k = h | sg << 1: (Q5, Q6, Q7, Q8) = sg
+                    v[h | (sg << 1)] = to_v(own[b3l + 32 * (sg & 1) + 16 * ((sg >> 1) & 1) + 8 * ((sg >> 2) & 1) + 4 * ((sg >> 3) & 1)]);
+                wfence();
+            }
+        }
+        dit_stages<32, m, 4, 6, 4, true, true>(v, to_v(lds[H2_TC + (l5 & 15)]));
+        // ---- E4 (cross-wave): registers Q4..Q8 -> Q7..Q11, round = Q8. Identity weights on the reduced index
+        // (Q0..Q7, Q9, Q10, Q11); the writer's wave is Q11, the reader's thread Q0..Q6
+        v2f y[P];
+        {
+            const int t = thread();
+            const int ln = t & 63, w = t >> 6;
+            const int b4s = (ln & 15) + 256 * ((ln >> 4) & 1) + 512 * ((ln >> 5) & 1) + 1024 * w;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                __syncthreads();  // (the other wave is done with this wave's half: E3, or the round before)
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk)  // register 16 h + kk: (Q4..Q7) = kk
+                    lds[b4s + 16 * kk] = to_f2(v[16 * h + kk]);
+                __syncthreads();
+#pragma unroll
+                for (int rr = 0; rr < 16; ++rr) {  // register (Q7, Q9, Q10, Q11) = rr, Q8 = h
+                    const int rg = (rr & 1) | (h << 1) | ((rr >> 1) << 2);
+                    y[rg] = to_v(lds[t + 128 * (rr & 1) + 256 * ((rr >> 1) & 1) + 512 * ((rr >> 2) & 1) + 1024 * ((rr >> 3) & 1)]);
                 }
             }
-#pragma unroll
-            for (int q = 0; q < PH; ++q) tail[q] = y[q + PH];
+            __syncthreads();
+        }
+        dit_stages<32, m, 7, 11, 7, true, true>(y, to_v(lds[H2_TA + thread()]));
+        {
+            const int t = thread();
+            hopw_epilogue<PITCH1, T>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[H2_TH + 2 * t]), to_v(lds[H2_TH + 2 * t + 1]),
+                                     to_v(lds[H2_TH + 256 + 2 * t]), to_v(lds[H2_TH + 256 + 2 * t + 1]), HANN_W13K, HANN_E13,
+                                     (float)(0.5 * HANN_KAPPA13), pitch);
         }
     }
 }
@@ -378,6 +613,15 @@ hipError_t launch_hopw(const HopParams &p, hipStream_t s) {
     const size_t lds = sizeof(float2) * (size_t)HOPW_LDS_FLOAT2;
     if (p.pitch == 1) hipLaunchKernelGGL((hopw_kernel<true>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((hopw_kernel<false>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+// N = 8192, fused path, default hanning window (HopParams::hann_rot set: [2][128][4]).
+hipError_t launch_hopw2(const HopParams &p, hipStream_t s) {
+    const dim3 grid(p.runs_per_channel * p.n_channels), block(128);
+    const size_t lds = sizeof(float2) * (size_t)HOPW2_LDS_FLOAT2;
+    if (p.pitch == 1) hipLaunchKernelGGL((hopw2_kernel<true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((hopw2_kernel<false>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 

@@ -150,6 +150,9 @@ bool hop_geometry(int log2n, int *threads, size_t *lds_bytes);
 // Workgroups of the fused kernel that share a CU when the kernel variant fixes it (0: derive it
 // from hop_geometry's LDS size). The run planner sizes a launch to two rounds of them.
 int hop_workgroups_per_cu(int log2n, bool default_window);
+// Workgroups per CU of the wave-local kernels (rc_hopw.hip: N = 4096 / 8192 with the default window), 0 otherwise:
+// all runs are equally long, so the planner launches whole multiples of what is resident at once.
+int hop_resident_workgroups(int log2n, bool default_window);
 // Launchers. Return hipSuccess or the launch error. log2n in [5, 14].
 hipError_t launch_hop(int log2n, HopMode mode, const HopParams &p, hipStream_t s);
 // (between translation units) the N = 16384 fused path: rc_hop16k.hip, and rc_hop16k_prev.hip in the test-hook library
@@ -157,6 +160,8 @@ hipError_t launch_hop16k(const HopParams &p, hipStream_t s);
 hipError_t launch_hop16k_prev(const HopParams &p, hipStream_t s);
 // N = 4096, fused path, default window: one wave per hop (rc_hopw.hip)
 hipError_t launch_hopw(const HopParams &p, hipStream_t s);
+// N = 8192 with the default window: two waves per hop (rc_hopw.hip)
+hipError_t launch_hopw2(const HopParams &p, hipStream_t s);
 // tail_only: just save y_{last}[H..] of the chunk as the carried tail (no output written)
 hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only = false);
 // stage 0 = A (forward quarter FFTs), 1 = B (radix-4 + middle + radix-4), 2 = C (inverse quarter FFTs)

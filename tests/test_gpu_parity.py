@@ -1065,14 +1065,16 @@ def test_non_power_of_two_window_refft_device_kernel_and_streaming():
 
 
 @pytest.mark.parametrize("p", [1, 2, 3])
-def test_4096_wave_per_hop_kernel_every_sample_and_ranges(p):
-    """hopw_kernel (window 4096, default hanning: one wave per hop, every exchange wave-local): a mid-size stereo job
-    on every sample against the oracle (thousands of runs: first-hop recompute at every run start, the end of the
-    stream, lane 0's self-paired bins), per-half-window blocks, and bit-equality of every shard plan with the whole job."""
+@pytest.mark.parametrize("N", [4096, 8192])
+def test_4096_8192_wave_local_kernels_every_sample_and_ranges(N, p):
+    """hopw_kernel (window 4096, default hanning: one wave per hop, every exchange wave-local) and hopw2_kernel (8192:
+    two waves per hop, the bin-order exchanges wave-local): a mid-size stereo job on every sample against the oracle
+    (thousands of runs: first-hop recompute at every run start, the end of the stream, thread 0's self-paired bins),
+    per-half-window blocks, and bit-equality of every shard plan with the whole job."""
     import torch
 
     ra = _engine_mod()
-    N, f, L, seed = 4096, 8.0, 900_000, 0xABCD
+    f, L, seed = 8.0, 900_000 * (N // 4096), 0xABCD
     x = np.stack([onp.synth_input(c, L) for c in range(2)])
     xt = torch.from_numpy(x).cuda()
     with ra.Engine(window_len=N, factor=f, pitch_multiple=p, channels=2, seed=seed) as e:
@@ -1082,8 +1084,8 @@ def test_4096_wave_per_hop_kernel_every_sample_and_ranges(p):
         ref = oc.stretch_offline(x, N, f, 1.0, p, seed=seed)
         assert got.shape == ref.shape
         for c in range(2):
-            assert_parity(got[c], ref[c], f"hopw p={p} ch{c}")
-        assert_blocks(got, ref, N // 2, f"hopw p={p}")
+            assert_parity(got[c], ref[c], f"hopw N={N} p={p} ch{c}")
+        assert_blocks(got, ref, N // 2, f"hopw N={N} p={p}")
         from rocoder_amd.distributed import engine_compute, shard_plan
 
         wout = e.params.window_out_len
@@ -1105,4 +1107,4 @@ def test_4096_wave_per_hop_kernel_every_sample_and_ranges(p):
     wins = []
     while not st.is_done():
         wins.append(st.next_window())
-    assert_parity(got1, np.concatenate(wins), f"4096 table window p={p}")
+    assert_parity(got1, np.concatenate(wins), f"{N} table window p={p}")
