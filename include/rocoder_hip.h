@@ -51,7 +51,7 @@ typedef int (*rc_freq_kernel)(uint64_t time_ms, const float *in_reim, float *out
 /* Stretcher::new arguments (src/stretcher.rs:30-39) + main.rs:131-147 call-site values. */
 typedef struct rc_config {
     uint32_t struct_size;    /* = sizeof(rc_config), ABI guard */
-    uint32_t window_len;     /* -w/--window (src/main.rs:34); power of two, 32..65536 */
+    uint32_t window_len;     /* -w/--window (src/main.rs:34); even, 4..65536 (powers of two: the fast kernels) */
     float factor;            /* -f/--factor (src/main.rs:46-52) */
     float amplitude;         /* -a/--amplitude */
     int32_t pitch_multiple;  /* -p/--pitch_multiple, i8 in the reference, != 0 */

@@ -21,6 +21,7 @@
 #include <string>
 #include <system_error>
 #include <thread>
+#include <complex>
 #include <vector>
 
 namespace {
@@ -192,8 +193,10 @@ struct rc_engine {
     rc_config cfg{};
     rc_params par{};
     int log2n = 0;     // 0: window_len is not a power of two (gen)
-    bool gen = false;  // O(N^2) DFT path for window lengths that are not a power of two
+    bool gen = false;  // window length that is not a power of two: chirp-z transforms (launch_gen)
     float2 *d_tw_gen = nullptr;  // gen: exp(-2 pi i k / N), k < N
+    float2 *d_bl_tab = nullptr;  // gen: chirp-z tables (HopParams::bl_tab)
+    uint32_t bl_log2l = 0;
     int device = 0;
     hipStream_t stream = nullptr;
     // event pairs around the kernel launches of the last RC_TIMING_RING offline calls (measurement)
@@ -335,6 +338,8 @@ rc::HopParams base_params(const rc_engine *e) {
     p.seed_mixed = e->seed_mixed;
     p.n_generic = e->gen ? e->par.window_len : 0;
     p.tw_generic = e->d_tw_gen;
+    p.bl_log2l = e->bl_log2l;
+    p.bl_tab = e->d_bl_tab;
     p.err_word = e->d_err;
     p.diag_flags = e->diag_flags;
     // 2^22 polls of ~2 000 cycles each (seconds); the diagnostic build of the protocol gives up at once
@@ -415,6 +420,8 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
         if (int rc = kp.d_ybuf[i].reserve(chunk_bytes / 2)) return rc;
         if (big)
             if (int rc = kp.d_ysub[i].reserve(chunk_bytes / 2)) return rc;
+        if (e->bl_log2l > 14)  // chirp-z work buffer: L points per hop
+            if (int rc = kp.d_ysub[i].reserve(((size_t)kc_max * n_channels * sizeof(float2)) << e->bl_log2l)) return rc;
     }
     if (kp.h_cap < chunk_bytes) {
         for (int i = 0; i < kSets; ++i) {
@@ -442,6 +449,7 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
         q.n_channels = n_channels;
         q.hop_first = k0;
         q.hop_count = kc;
+        if (e->bl_log2l > 14) q.bl_wk = (float2 *)kp.d_ysub[set].p;
         if (big) {
             *b = big_params(e, q);
             b->ysub = (float2 *)kp.d_ysub[set].p;
@@ -461,6 +469,9 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
             RC_HIP(rc::launch_big(0, b, kp.kf));
             RC_HIP(rc::launch_big(1, b, kp.kf, rc::MODE_FORWARD));
             *launches += 2;
+        } else if (e->gen) {
+            RC_HIP(rc::launch_gen(0, q, kp.kf));
+            *launches += 1;
         } else {
             RC_HIP(rc::launch_hop(e->log2n, rc::MODE_FORWARD, q, kp.kf));
             *launches += 1;
@@ -507,6 +518,10 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
         if (big) {
             RC_HIP(rc::launch_big(1, b, kp.kb, rc::MODE_RESYNTH));
             RC_HIP(rc::launch_big(2, b, kp.kb));
+            *launches += 2;
+        } else if (e->gen) {
+            RC_HIP(rc::launch_gen(1, q, kp.kb));
+            RC_HIP(rc::launch_gen(2, q, kp.kb));
             *launches += 2;
         } else {
             RC_HIP(rc::launch_hop(e->log2n, rc::MODE_RESYNTH, q, kp.kb));
@@ -772,7 +787,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     RC_HIP(rc::launch_prep(prep, s));
     const bool big = e->log2n > 14;
     const uint32_t hpw = e->par.hops_per_window;
-    const size_t per_hop = (size_t)N * (devk ? 28 : 12);  // spectrum(s) / quarter-FFT scratch, y
+    const size_t per_hop = (size_t)N * (devk ? 28 : 12) + (e->bl_log2l > 14 ? sizeof(float2) << e->bl_log2l : 0);  // spectrum(s) / quarter-FFT scratch, y
     int64_t chunk_max = (int64_t)(((size_t)1024 << 20) / (per_hop * n_channels));
     chunk_max = std::max<int64_t>(hpw, std::min<int64_t>(chunk_max / hpw * hpw, 32768));
     int rc = e->d_tail.reserve((size_t)e->cfg.channels * H * sizeof(float));
@@ -791,6 +806,10 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         rc::HopParams q = p;
         q.spec = (float2 *)e->d_spec.p;
         q.ybuf = (float *)e->d_ybuf.p;
+        if (e->bl_log2l > 14) {  // chirp-z transforms longer than one workgroup's LDS: work buffer of L points per hop
+            if ((rcc = e->d_ysub.reserve(((size_t)n_channels * kc * sizeof(float2)) << e->bl_log2l))) return rcc;
+            q.bl_wk = (float2 *)e->d_ysub.p;
+        }
         q.ch_first = ch_first;
         q.n_channels = n_channels;
         q.hop_first = k0;
@@ -837,7 +856,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
             launches += 3;
             return RC_OK;
         } else if (e->gen) {
-            // window length that is not a power of two: O(N^2) DFTs, optional device kernel in between
+            // window length that is not a power of two: chirp-z transforms, optional device kernel in between
             RC_HIP(rc::launch_gen(0, q, s));
             if (devk) {
                 rc::DevKernelParams d{};
@@ -944,7 +963,12 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
 // one hop described by p (spec / ybuf set) on the engine's stream, any supported window length
 int single_hop_forward(rc_engine *e, const rc::HopParams &p) {
     if (e->gen) {
-        RC_HIP(rc::launch_gen(0, p, e->stream));
+        rc::HopParams g = p;
+        if (e->bl_log2l > 14) {
+            if (int rcw = e->d_ysub.reserve(sizeof(float2) << e->bl_log2l)) return rcw;
+            g.bl_wk = (float2 *)e->d_ysub.p;
+        }
+        RC_HIP(rc::launch_gen(0, g, e->stream));
         return RC_OK;
     }
     if (e->log2n <= 14) {
@@ -962,8 +986,13 @@ int single_hop_forward(rc_engine *e, const rc::HopParams &p) {
 }
 int single_hop_resynth(rc_engine *e, const rc::HopParams &p) {
     if (e->gen) {  // (p.spec holds the spectrum: magnitudes x phasors in place, then the inverse DFT)
-        RC_HIP(rc::launch_gen(1, p, e->stream));
-        RC_HIP(rc::launch_gen(2, p, e->stream));
+        rc::HopParams g = p;
+        if (e->bl_log2l > 14) {
+            if (int rcw = e->d_ysub.reserve(sizeof(float2) << e->bl_log2l)) return rcw;
+            g.bl_wk = (float2 *)e->d_ysub.p;
+        }
+        RC_HIP(rc::launch_gen(1, g, e->stream));
+        RC_HIP(rc::launch_gen(2, g, e->stream));
         return RC_OK;
     }
     if (e->log2n <= 14) {
@@ -1055,8 +1084,6 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
     // -w through rustfft: src/main.rs:34, src/fft.rs:27-29) runs as plain O(N^2) DFTs on the device: correct,
     // not fast, and without a host frequency kernel.
     const bool gen = log2n < 0 && cfg->window_len >= 4 && cfg->window_len <= 65536 && cfg->window_len % 2 == 0;
-    if (gen && cfg->kernel)
-        return fail(RC_EUNSUPPORTED, "window_len %u is not a power of two: host frequency kernels need one (device kernels work)", cfg->window_len);
     if (!gen && (log2n < 5 || log2n > 16))
         return fail(RC_EUNSUPPORTED, "window_len %u: the GPU path supports powers of two in [32, 65536] and even lengths in [4, 65536]", cfg->window_len);
     if (gen) log2n = 0;
@@ -1127,6 +1154,38 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
             twg[k] = make_float2((float)cos(a), (float)sin(a));
         }
     }
+    // chirp-z tables for the lengths whose packed half fits the LDS (bluestein_kernel), all in f64 first
+    std::vector<float2> blt;
+    uint32_t bl_log2l = 0;
+    if (gen && RC_BLUESTEIN) {
+        const uint32_t Mh = N / 2;
+        while ((1u << bl_log2l) < 2 * Mh - 1 || bl_log2l < 1) ++bl_log2l;
+        const uint32_t L = 1u << bl_log2l;
+        blt.resize((size_t)Mh + L / 2 + L);
+        std::vector<std::complex<double>> c(Mh), b(L, 0.0), w(L / 2);
+        for (uint32_t n = 0; n < Mh; ++n) {
+            const uint64_t r = ((uint64_t)n * n) % (2ull * Mh);  // n^2 mod 2M: the angle stays exact
+            c[n] = std::polar(1.0, -M_PI * (double)r / (double)Mh);
+            blt[n] = make_float2((float)c[n].real(), (float)c[n].imag());
+            b[n] = std::conj(c[n]);
+            if (n) b[L - n] = std::conj(c[n]);
+        }
+        for (uint32_t k = 0; k < L / 2; ++k) {
+            w[k] = std::polar(1.0, -2.0 * M_PI * (double)k / (double)L);
+            blt[Mh + k] = make_float2((float)w[k].real(), (float)w[k].imag());
+        }
+        for (int s = (int)bl_log2l - 1; s >= 0; --s) {  // the kernel's DIF (natural -> bit-reversed order)
+            const uint32_t half = 1u << s;
+            for (uint32_t q = 0; q < L / 2; ++q) {
+                const uint32_t lo = q & (half - 1), i = ((q >> s) << (s + 1)) | lo, j = i + half;
+                const std::complex<double> u = b[i], v = b[j];
+                b[i] = u + v;
+                b[j] = (u - v) * w[(size_t)lo << (bl_log2l - 1 - s)];
+            }
+        }
+        for (uint32_t i = 0; i < L; ++i)
+            blt[(size_t)Mh + L / 2 + i] = make_float2((float)(b[i].real() / L), (float)(b[i].imag() / L));
+    }
     const uint32_t Mf = big ? M / 4 : M;  // length of the in-LDS FFT
     std::vector<float2> wtab(std::max<uint32_t>(1, Mf / 2)), rtab(big ? Mf / 2 + 1 : M / 4 + 1), t1;
     for (uint32_t k = 0; k < Mf / 2; ++k) {
@@ -1186,6 +1245,11 @@ int rc_engine_create(const rc_config *cfg, rc_engine **out) try {
         RC_HIP_C(hipMalloc((void **)&e->d_tw_gen, twg.size() * sizeof(float2)));
         RC_HIP_C(hipMemcpy(e->d_tw_gen, twg.data(), twg.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
+    if (!blt.empty()) {
+        RC_HIP_C(hipMalloc((void **)&e->d_bl_tab, blt.size() * sizeof(float2)));
+        RC_HIP_C(hipMemcpy(e->d_bl_tab, blt.data(), blt.size() * sizeof(float2), hipMemcpyHostToDevice));
+        e->bl_log2l = bl_log2l;
+    }
     if (big) {
         RC_HIP_C(hipMalloc((void **)&e->d_t1, t1.size() * sizeof(float2)));
         RC_HIP_C(hipMemcpy(e->d_t1, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice));
@@ -1216,6 +1280,7 @@ void rc_engine_destroy(rc_engine *e) {
     if (e->d_t1) (void)hipFree(e->d_t1);
     if (e->d_wtab_m) (void)hipFree(e->d_wtab_m);
     if (e->d_tw_gen) (void)hipFree(e->d_tw_gen);
+    if (e->d_bl_tab) (void)hipFree(e->d_bl_tab);
     e->d_in.release();
     e->d_out.release();
     e->d_spec.release();

@@ -227,7 +227,7 @@ __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, cons
 
 template <bool PITCH1>
 __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
-    constexpr int LOG2N = 12, m = 11, M = 1 << m, H = M, T = 64, P = 32, PH = 16, RES = 128;
+    constexpr int LOG2N = 12, m = 11, T = 64, P = 32, PH = 16, RES = 128;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const uint32_t run = blockIdx.x % p.runs_per_channel;

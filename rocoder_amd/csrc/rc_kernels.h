@@ -8,6 +8,12 @@ namespace rc {
 
 // One launch = channels [0, n_channels) x hops [hop_first, hop_first + hop_count), cut into
 // `runs_per_channel` contiguous runs of `run_len` hops; one workgroup walks one run.
+// 0: variant builds only (tools/build_variant.sh x -DRC_BLUESTEIN=0) - window lengths that are not a power of two run
+// the first implementation's O(N^2) DFT kernels instead of the chirp-z transforms, as an independent A/B partner
+#ifndef RC_BLUESTEIN
+#define RC_BLUESTEIN 1
+#endif
+
 struct HopParams {
     const float *x;        // channel c at x + c * in_stride; x[0] is absolute sample `in_origin`
     size_t in_stride;
@@ -64,6 +70,12 @@ struct HopParams {
     // window lengths that are not a power of two (launch_gen): N and exp(-2 pi i k / N), k < N
     uint32_t n_generic;
     const float2 *tw_generic;
+    // ... of them, the lengths N <= 16384 run chirp-z (Bluestein) transforms of the packed N/2-point sequence in LDS:
+    // bl_log2l = log2 of the convolution length L >= N - 1 (0: the O(N^2) DFT kernels), bl_tab = [N/2] chirp
+    // exp(-i pi n^2 / (N/2)) | [L/2] exp(-2 pi i k / L) | [L] FFT_L of the conjugate chirp / L in bit-reversed order
+    uint32_t bl_log2l;
+    const float2 *bl_tab;
+    float2 *bl_wk;         // L > 16384 only: [n_channels][hop_count][L] work buffer (the FFT_L then runs in three kernels)
 };
 
 struct OlaParams {

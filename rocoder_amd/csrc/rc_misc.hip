@@ -83,7 +83,9 @@ hipError_t launch_dev_kernel(const DevKernelParams &p, hipStream_t s) {
     return hipSuccess;
 }
 
-// ---- window lengths that are not a power of two: O(N^2) DFTs (rc_kernels.h, launch_gen) -----------
+// ---- window lengths that are not a power of two (rc_kernels.h, launch_gen) -----------
+#if !RC_BLUESTEIN
+// O(N^2) DFTs: the first implementation, kept for A/B builds
 __global__ __launch_bounds__(256) void gen_fwd_kernel(const HopParams p) {
     const uint32_t N = p.n_generic;
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -109,6 +111,8 @@ __global__ __launch_bounds__(256) void gen_fwd_kernel(const HopParams p) {
     }
     stg2((GV2W)p.spec + ((size_t)ch * p.hop_count + (size_t)hl) * N + k, make_float2(ax, ay));
 }
+#endif
+// magnitudes x phasors in place on all N bins (between the two transforms)
 __global__ __launch_bounds__(256) void gen_phase_kernel(const HopParams p) {
     const uint32_t N = p.n_generic, half = N / 2;
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,6 +132,7 @@ __global__ __launch_bounds__(256) void gen_phase_kernel(const HopParams p) {
     sincosf(th, &sn, &cs);
     stg2(z, make_float2(m * cs, m * sn));  // src/fft.rs:65-68
 }
+#if !RC_BLUESTEIN
 __global__ __launch_bounds__(256) void gen_inv_kernel(const HopParams p) {
     const uint32_t N = p.n_generic;
     const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -146,6 +151,237 @@ __global__ __launch_bounds__(256) void gen_inv_kernel(const HopParams p) {
     }
     ((GFW)p.ybuf)[((size_t)ch * p.hop_count + (size_t)hl) * N + n] = acc / (float)N * ((GF)p.window)[n];  // fft.rs:70-73
 }
+#endif
+
+// ---- ... and chirp-z (Bluestein) transforms for the lengths whose packed half fits the LDS (N <= 16384) -----------
+// The window is real and N even: z[n] = x[2n] + i x[2n+1] (M = N/2 points), Z = DFT_M(z) by
+//   n k = (n^2 + k^2 - (k - n)^2) / 2  =>  Z[k] = c[k] sum_n (z[n] c[n]) conj(c)[k - n],  c[n] = exp(-i pi n^2 / M):
+// a circular convolution of length L = 2^l >= 2M - 1 = one DIF FFT_L (natural -> bit-reversed), a pointwise product
+// with the precomputed FFT_L of conj(c) (stored bit-reversed, 1/L folded in), one DIT inverse FFT_L (bit-reversed ->
+// natural): no bit reversal anywhere. Then the real split X[j] = E[j] + W_N^j O[j] (src/fft.rs:50-61 computes the full
+// complex N-point FFT of the real frame: the upper half is its conjugate mirror). The inverse takes the N resynthesised
+// bins (independent phases: not Hermitian), keeps the Hermitian part - Re(IFFT(Z)) = IFFT((Z + conj(mirror Z)) / 2),
+// src/fft.rs:69-73 - merges it to M packed bins and runs the same transform on the conjugate.
+// One workgroup per hop; radix-2 stages in place in LDS (a path for odd window lengths of the CLI's -w, built for
+// O(N log N) instead of O(N^2), not for the roofline).
+constexpr uint32_t BL_BLOCK = 16384;  // points of an FFT_L that one workgroup holds in LDS
+
+struct BlCtx {
+    uint32_t N, M, l2, L;
+    GV2 chirp, twl, bbr, twn;
+    GF win;
+    size_t row;   // first element of this (channel, hop) in spec / ybuf
+    size_t rowl;  // ... in bl_wk
+};
+__device__ __forceinline__ BlCtx bl_ctx(const HopParams &p, int64_t hl, uint32_t ch) {
+    BlCtx c;
+    c.N = p.n_generic;
+    c.M = c.N / 2;
+    c.l2 = p.bl_log2l;
+    c.L = 1u << c.l2;
+    c.chirp = (GV2)p.bl_tab;
+    c.twl = c.chirp + c.M;
+    c.bbr = c.twl + c.L / 2;
+    c.twn = (GV2)p.tw_generic;
+    c.win = (GF)p.window;
+    c.row = ((size_t)ch * p.hop_count + (size_t)hl) * c.N;
+    c.rowl = ((size_t)ch * p.hop_count + (size_t)hl) * c.L;
+    return c;
+}
+// element n of the sequence the forward / inverse transform convolves (zero from M on)
+__device__ __forceinline__ float2 bl_in_fwd(const BlCtx &c, GF src, uint32_t n) {
+    if (n >= c.M) return make_float2(0.f, 0.f);
+    return cmul(make_float2(src[2 * n] * c.win[2 * n], src[2 * n + 1] * c.win[2 * n + 1]), ldg2(c.chirp + n));
+}
+__device__ __forceinline__ float2 bl_in_inv(const BlCtx &c, GV2 Z, uint32_t k) {
+    if (k >= c.M) return make_float2(0.f, 0.f);
+    const float2 z0 = ldg2(Z + k), z0m = ldg2(Z + (k ? c.N - k : 0)), z1 = ldg2(Z + k + c.M), z1m = ldg2(Z + c.M - k);
+    // Hermitian part at k and k + M, then even / odd halves: E = (Zh[k] + Zh[k+M]) / 2, W^k O = (Zh[k] - Zh[k+M]) / 2
+    const float2 h0 = make_float2(0.5f * (z0.x + z0m.x), 0.5f * (z0.y - z0m.y));
+    const float2 h1 = make_float2(0.5f * (z1.x + z1m.x), 0.5f * (z1.y - z1m.y));
+    const float2 E = make_float2(0.5f * (h0.x + h1.x), 0.5f * (h0.y + h1.y));
+    const float2 D = make_float2(0.5f * (h0.x - h1.x), 0.5f * (h0.y - h1.y));
+    const float2 w = ldg2(c.twn + k);
+    const float2 O = cmul(D, make_float2(w.x, -w.y));
+    const float2 G = make_float2(E.x - O.y, E.y + O.x);      // E + i O
+    return cmul(make_float2(G.x, -G.y), ldg2(c.chirp + k));  // IDFT_M(G) = conj(DFT_M(conj G)) / M
+}
+__device__ __forceinline__ GF bl_src(const HopParams &p, int64_t hl, uint32_t ch) {
+    const int64_t hop = p.hop_first + hl;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    return (hop >= p.tail_hop_first) ? xt + (hop * (int64_t)p.step - p.tail_origin) : xc + (hop * (int64_t)p.step - p.in_origin);
+}
+// real split of Z = DFT_M(z) (zj = Z[j mod M], zm = Z[(M - j) mod M]) into bin j of the N-point spectrum and its mirror
+__device__ __forceinline__ void bl_split_store(const BlCtx &c, GV2W X, uint32_t j, float2 zj, float2 zm) {
+    const float2 E = make_float2(0.5f * (zj.x + zm.x), 0.5f * (zj.y - zm.y));
+    const float2 O = make_float2(0.5f * (zj.y + zm.y), -0.5f * (zj.x - zm.x));  // (zj - conj zm) / (2 i)
+    const float2 t = cmul(O, ldg2(c.twn + j));
+    const float2 x = make_float2(E.x + t.x, E.y + t.y);
+    stg2(X + j, x);
+    if (j > 0 && j < c.M) stg2(X + (c.N - j), make_float2(x.x, -x.y));
+}
+// v = (convolution output)[n]: conj(v c[n]) / M = (y[2n], y[2n+1]) of IDFT_N; times the window (fft.rs:70-73)
+__device__ __forceinline__ void bl_out_inv(const BlCtx &c, GFW y, uint32_t n, float2 v) {
+    const float2 r = cmul(v, ldg2(c.chirp + n));
+    const float inv = 1.0f / (float)c.M;
+    y[2 * n] = r.x * inv * c.win[2 * n];
+    y[2 * n + 1] = -r.y * inv * c.win[2 * n + 1];
+}
+// radix-2 stages s_hi .. s_lo (DIF, descending) or s_lo .. s_hi (DIT with conjugate twiddles, ascending) of an FFT_L on
+// `cnt` points in LDS whose index bits above the block are `base` (twiddles depend on the index below the stage only)
+template <bool DIT>
+__device__ __forceinline__ void bl_lds_stages(float2 *a, uint32_t cnt, int s_lo, int s_hi, uint32_t l2, GV2 twl) {
+    const uint32_t T = blockDim.x, tid = threadIdx.x;
+    for (int q = 0; q <= s_hi - s_lo; ++q) {
+        const int s = DIT ? s_lo + q : s_hi - q;
+        const uint32_t half = 1u << s;
+        for (uint32_t b = tid; b < cnt / 2; b += T) {
+            const uint32_t lo = b & (half - 1), i = ((b >> s) << (s + 1)) | lo, j = i + half;
+            const float2 w = ldg2(twl + ((size_t)lo << (l2 - 1 - s)));
+            if (DIT) {
+                const float2 u = a[i], v = cmul(a[j], make_float2(w.x, -w.y));
+                a[i] = make_float2(u.x + v.x, u.y + v.y);
+                a[j] = make_float2(u.x - v.x, u.y - v.y);
+            } else {
+                const float2 u = a[i], v = a[j];
+                a[i] = make_float2(u.x + v.x, u.y + v.y);
+                a[j] = cmul(make_float2(u.x - v.x, u.y - v.y), w);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// L <= 16384: the whole transform in one workgroup
+template <bool INV>
+__global__ __launch_bounds__(1024) void bluestein_kernel(const HopParams p) {
+    extern __shared__ __attribute__((aligned(16))) float2 a[];
+    const int64_t hl = blockIdx.x;
+    const uint32_t ch = blockIdx.y, T = blockDim.x, tid = threadIdx.x;
+    const BlCtx c = bl_ctx(p, hl, ch);
+    if (!INV) {
+        GF src = bl_src(p, hl, ch);
+        for (uint32_t n = tid; n < c.L; n += T) a[n] = bl_in_fwd(c, src, n);
+    } else {
+        GV2 Z = (GV2)p.spec + c.row;
+        for (uint32_t k = tid; k < c.L; k += T) a[k] = bl_in_inv(c, Z, k);
+    }
+    __syncthreads();
+    bl_lds_stages<false>(a, c.L, 0, (int)c.l2 - 1, c.l2, c.twl);  // DIF, natural -> bit-reversed
+    for (uint32_t i = tid; i < c.L; i += T) a[i] = cmul(a[i], ldg2(c.bbr + i));
+    __syncthreads();
+    bl_lds_stages<true>(a, c.L, 0, (int)c.l2 - 1, c.l2, c.twl);   // DIT, bit-reversed -> natural
+    if (!INV) {
+        for (uint32_t k = tid; k < c.M; k += T) a[k] = cmul(a[k], ldg2(c.chirp + k));  // Z = DFT_M(z)
+        __syncthreads();
+        GV2W X = (GV2W)p.spec + c.row;
+        for (uint32_t j = tid; j <= c.M; j += T) bl_split_store(c, X, j, a[j == c.M ? 0 : j], a[j == 0 ? 0 : c.M - j]);
+    } else {
+        GFW y = (GFW)p.ybuf + c.row;
+        for (uint32_t n = tid; n < c.M; n += T) bl_out_inv(c, y, n, a[n]);
+    }
+}
+
+// L = 2^LB x 16384 (N up to 65536): the top LB stages in registers through the work buffer, the rest per block in LDS
+//   bl_top_kernel<INV, LB>   builds the sequence and runs DIF stages l2-1 .. 14     (grid: 64 x hops x channels, 256 threads)
+//   bl_block_kernel          per 16384-point block: DIF 13 .. 0, x FFT(conj chirp), DIT 0 .. 13   (2^LB x hops x channels)
+//   bl_bottom_kernel<INV,LB> DIT stages 14 .. l2-1; forward: Z = y c into the work buffer; inverse: the output samples
+//   bl_split_kernel          forward only: real split of Z into the N bins
+template <bool INV, int LB>
+__global__ __launch_bounds__(256) void bl_top_kernel(const HopParams p) {
+    constexpr uint32_t B = 1u << LB;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.z;
+    const int64_t hl = blockIdx.y;
+    const BlCtx c = bl_ctx(p, hl, ch);
+    float2 v[B];
+    if (!INV) {
+        GF src = bl_src(p, hl, ch);
+#pragma unroll
+        for (uint32_t q = 0; q < B; ++q) v[q] = bl_in_fwd(c, src, i + q * BL_BLOCK);
+    } else {
+        GV2 Z = (GV2)p.spec + c.row;
+#pragma unroll
+        for (uint32_t q = 0; q < B; ++q) v[q] = bl_in_inv(c, Z, i + q * BL_BLOCK);
+    }
+#pragma unroll
+    for (int t = LB - 1; t >= 0; --t) {  // stage s = 14 + t pairs q and q + 2^t
+#pragma unroll
+        for (uint32_t q = 0; q < B; ++q) {
+            if (q & (1u << t)) continue;
+            const uint32_t lo = i + (q & ((1u << t) - 1)) * BL_BLOCK;
+            const float2 w = ldg2(c.twl + ((size_t)lo << (LB - 1 - t)));  // l2 - 1 - s = LB - 1 - t
+            const float2 u = v[q], x = v[q | (1u << t)];
+            v[q] = make_float2(u.x + x.x, u.y + x.y);
+            v[q | (1u << t)] = cmul(make_float2(u.x - x.x, u.y - x.y), w);
+        }
+    }
+    GV2W wk = (GV2W)p.bl_wk + c.rowl;
+#pragma unroll
+    for (uint32_t q = 0; q < B; ++q) stg2(wk + i + q * BL_BLOCK, v[q]);
+}
+__global__ __launch_bounds__(1024) void bl_block_kernel(const HopParams p) {
+    extern __shared__ __attribute__((aligned(16))) float2 a[];
+    const uint32_t blk = blockIdx.x, ch = blockIdx.z, T = blockDim.x, tid = threadIdx.x;
+    const BlCtx c = bl_ctx(p, blockIdx.y, ch);
+    GV2W wk = (GV2W)p.bl_wk + c.rowl + (size_t)blk * BL_BLOCK;
+    for (uint32_t i = tid; i < BL_BLOCK; i += T) a[i] = ldg2((GV2)wk + i);
+    __syncthreads();
+    bl_lds_stages<false>(a, BL_BLOCK, 0, 13, c.l2, c.twl);
+    for (uint32_t i = tid; i < BL_BLOCK; i += T) a[i] = cmul(a[i], ldg2(c.bbr + (size_t)blk * BL_BLOCK + i));
+    __syncthreads();
+    bl_lds_stages<true>(a, BL_BLOCK, 0, 13, c.l2, c.twl);
+    for (uint32_t i = tid; i < BL_BLOCK; i += T) stg2(wk + i, a[i]);
+}
+template <bool INV, int LB>
+__global__ __launch_bounds__(256) void bl_bottom_kernel(const HopParams p) {
+    constexpr uint32_t B = 1u << LB;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.z;
+    const BlCtx c = bl_ctx(p, blockIdx.y, ch);
+    GV2W wk = (GV2W)p.bl_wk + c.rowl;
+    float2 v[B];
+#pragma unroll
+    for (uint32_t q = 0; q < B; ++q) v[q] = ldg2((GV2)wk + i + q * BL_BLOCK);
+#pragma unroll
+    for (int t = 0; t < LB; ++t) {
+#pragma unroll
+        for (uint32_t q = 0; q < B; ++q) {
+            if (q & (1u << t)) continue;
+            const uint32_t lo = i + (q & ((1u << t) - 1)) * BL_BLOCK;
+            const float2 w = ldg2(c.twl + ((size_t)lo << (LB - 1 - t)));
+            const float2 u = v[q], x = cmul(v[q | (1u << t)], make_float2(w.x, -w.y));
+            v[q] = make_float2(u.x + x.x, u.y + x.y);
+            v[q | (1u << t)] = make_float2(u.x - x.x, u.y - x.y);
+        }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < B; ++q) {
+        const uint32_t n = i + q * BL_BLOCK;
+        if (n >= c.M) continue;
+        if (!INV) stg2(wk + n, cmul(v[q], ldg2(c.chirp + n)));  // (every thread rewrites only what it read)
+        else bl_out_inv(c, (GFW)p.ybuf + c.row, n, v[q]);
+    }
+}
+__global__ __launch_bounds__(256) void bl_split_kernel(const HopParams p) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.z;
+    const BlCtx c = bl_ctx(p, blockIdx.y, ch);
+    if (j > c.M) return;
+    GV2 Z = (GV2)p.bl_wk + c.rowl;
+    bl_split_store(c, (GV2W)p.spec + c.row, j, ldg2(Z + (j == c.M ? 0 : j)), ldg2(Z + (j == 0 ? 0 : c.M - j)));
+}
+template <int LB>
+void launch_bl_large(int stage, const HopParams &q, unsigned ny, hipStream_t s) {
+    const dim3 gtop(BL_BLOCK / 256, ny, q.n_channels), gblk(1u << LB, ny, q.n_channels);
+    if (stage == 0) hipLaunchKernelGGL((bl_top_kernel<false, LB>), gtop, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((bl_top_kernel<true, LB>), gtop, dim3(256), 0, s, q);
+    hipLaunchKernelGGL(bl_block_kernel, gblk, dim3(1024), sizeof(float2) * (size_t)BL_BLOCK, s, q);
+    if (stage == 0) {
+        hipLaunchKernelGGL((bl_bottom_kernel<false, LB>), gtop, dim3(256), 0, s, q);
+        hipLaunchKernelGGL(bl_split_kernel, dim3((q.n_generic / 2 + 256) / 256, ny, q.n_channels), dim3(256), 0, s, q);
+    } else {
+        hipLaunchKernelGGL((bl_bottom_kernel<true, LB>), gtop, dim3(256), 0, s, q);
+    }
+}
 hipError_t launch_gen(int stage, const HopParams &p, hipStream_t s) {
     const uint32_t N = p.n_generic;
     const int64_t per = 32768;  // grid.y limit
@@ -158,9 +394,24 @@ hipError_t launch_gen(int stage, const HopParams &p, hipStream_t s) {
         q.spec = p.spec ? p.spec + (size_t)h0 * N : nullptr;
         q.ybuf = p.ybuf ? p.ybuf + (size_t)h0 * N : nullptr;
         const dim3 grid((N + 255) / 256, ny, p.n_channels), block(256);
-        if (stage == 0) hipLaunchKernelGGL(gen_fwd_kernel, grid, block, 0, s, q);
-        else if (stage == 1) hipLaunchKernelGGL(gen_phase_kernel, grid, block, 0, s, q);
+        if (p.bl_log2l > 16) return hipErrorInvalidValue;
+        if (p.bl_log2l > 14 && stage != 1) {
+            q.bl_wk = p.bl_wk ? p.bl_wk + ((size_t)h0 << p.bl_log2l) : nullptr;
+            if (!q.bl_wk) return hipErrorInvalidValue;
+            if (p.bl_log2l == 15) launch_bl_large<1>(stage, q, ny, s);
+            else launch_bl_large<2>(stage, q, ny, s);
+        } else if (p.bl_log2l && stage != 1) {
+            const uint32_t L = 1u << p.bl_log2l;
+            const dim3 bgrid(ny, p.n_channels), bblock(L / 2 < 64 ? 64 : (L / 2 > 1024 ? 1024 : L / 2));
+            if (stage == 0) hipLaunchKernelGGL(bluestein_kernel<false>, bgrid, bblock, sizeof(float2) * (size_t)L, s, q);
+            else hipLaunchKernelGGL(bluestein_kernel<true>, bgrid, bblock, sizeof(float2) * (size_t)L, s, q);
+        } else if (stage == 1) hipLaunchKernelGGL(gen_phase_kernel, grid, block, 0, s, q);
+#if !RC_BLUESTEIN
+        else if (stage == 0) hipLaunchKernelGGL(gen_fwd_kernel, grid, block, 0, s, q);
         else hipLaunchKernelGGL(gen_inv_kernel, grid, block, 0, s, q);
+#else
+        else return hipErrorInvalidValue;  // (the engine builds the chirp-z tables for every such length)
+#endif
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
