@@ -531,6 +531,7 @@ struct Opt {  // src/main.rs:27-122
     std::optional<std::string> output;
     uint64_t seed = 0;  // not in the reference: thread_rng there
     int device = 0;
+    std::vector<int32_t> devices;  // not in the reference: --devices a,b,... shards one job over several GPUs (rc_multi_*)
 };
 
 void usage() {
@@ -551,7 +552,8 @@ void usage() {
             "        --device-kernel <spec>         On-GPU frequency kernel: gain:<g> | band:<lo>:<hi>:<g_in>:<g_out> | shift:<bins>\n"
             "        --kernel-threads <n>           Host threads calling --freq-kernel (channels in parallel; needs a re-entrant kernel)\n"
             "        --seed <u64>                   Phase-source seed (the reference uses an unseeded thread_rng)\n"
-            "        --device <n>                   HIP device ordinal [default: 0]\n");
+            "        --device <n>                   HIP device ordinal [default: 0]\n"
+            "        --devices <a,b,...>            Shard the job over several GPUs (offline; not with --freq-kernel)\n");
 }
 
 int run(int argc, char **argv) {
@@ -601,6 +603,15 @@ int run(int argc, char **argv) {
         else if (a == "-o" || a == "--output") o.output = need(i);
         else if (a == "--seed") o.seed = strtoull(need(i).c_str(), nullptr, 0);
         else if (a == "--device") o.device = atoi(need(i).c_str());
+        else if (a == "--devices") {
+            const std::string v = need(i);
+            for (size_t b = 0; b <= v.size();) {
+                const size_t c = std::min(v.find(',', b), v.size());
+                if (c == b) throw std::runtime_error("bad --devices " + v);
+                o.devices.push_back((int32_t)atoi(v.substr(b, c - b).c_str()));
+                b = c + 1;
+            }
+        }
         else throw std::runtime_error("unknown argument " + a);
     }
     if (!o.input) throw std::runtime_error("recording from an input device (no -i) is not supported: pass -i <file.wav> or -i -");
@@ -668,6 +679,34 @@ int run(int argc, char **argv) {
         } else {
             throw std::runtime_error("bad --device-kernel " + *o.device_kernel);
         }
+    }
+    if (!o.devices.empty()) {
+        // several GPUs: the whole job at once through the multi-device entry (windows of a channel are independent
+        // given the phase source, so the devices share nothing but the input; include/rocoder_hip.h, rc_multi_*).
+        // Same samples as the Stretcher / StretcherProcessor loop below produces (tests/test_gpu_cli.py).
+        rc_multi *m = nullptr;
+        if (rc_multi_create(&cfg, o.devices.data(), (uint32_t)o.devices.size(), &m) != RC_OK)
+            throw std::runtime_error(std::string("rocoder_hip: ") + rc_last_error());
+        lap("engine create");
+        const size_t in_len = audio.data[0].size(), cap = rc_offline_output_len(&cfg, in_len);
+        Audio out;
+        out.spec = spec;
+        out.data.assign(spec.channels, std::vector<float>(cap));
+        std::vector<const float *> ins;
+        std::vector<float *> outs;
+        for (uint32_t c = 0; c < spec.channels; ++c) {
+            ins.push_back(audio.data[c].data());
+            outs.push_back(out.data[c].data());
+        }
+        size_t n = 0;
+        const int rc = rc_multi_stretch_host(m, ins.data(), in_len, outs.data(), cap, &n);
+        rc_multi_destroy(m);
+        if (rc != RC_OK) throw std::runtime_error(std::string("rocoder_hip: ") + rc_last_error());
+        for (auto &c : out.data) c.resize(n);
+        lap("stretch");
+        write_wav_f32(*o.output, out);
+        lap("write output");
+        return 0;
     }
     auto eng = std::make_shared<Engine>();
     if (rc_engine_create(&cfg, &eng->h) != RC_OK) throw std::runtime_error(std::string("rocoder_hip: ") + rc_last_error());

@@ -48,6 +48,34 @@ def test_cli_matches_oracle(tmp_path, fmt, extra, okw):
     check(got, oc.stretch_offline(dec, seed=77, **okw))
 
 
+@pytest.mark.parametrize("extra", [["-w", "16384", "-f", "8"], ["-w", "4096", "-f", "4", "-p", "3"],
+                                   ["-w", "3000", "-f", "2"], ["-w", "2048", "-f", "2", "-p", "-2"]])
+def test_cli_devices_list_writes_the_same_file(tmp_path, extra):
+    """--devices a,b,... (rc_multi_*: the job sharded over the listed GPUs; here the one GPU listed twice / three
+    times) writes byte for byte what the Stretcher / StretcherProcessor loop on one engine writes."""
+    x = np.stack([onp.synth_input(c, 150000) for c in range(3)])
+    wav = str(tmp_path / "in.wav")
+    write_wav(wav, x, 44100, "f32")
+    outs = []
+    for name, dev in (("one", []), ("two", ["--devices", "0,0"]), ("three", ["--devices", "0,0,0"])):
+        out = str(tmp_path / f"{name}.wav")
+        run("-i", wav, "-o", out, "--seed", "5", *extra, *dev)
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] == outs[2]
+    assert len(outs[0]) > 44 + 3 * 4 * 150000
+
+
+def test_cli_devices_refuses_host_kernels(tmp_path):
+    x = np.stack([onp.synth_input(c, 20000) for c in range(2)])
+    wav, out, src = str(tmp_path / "in.wav"), str(tmp_path / "o.wav"), str(tmp_path / "k.c")
+    write_wav(wav, x, 44100, "f32")
+    open(src, "w").write("#include <stddef.h>\n#include <stdint.h>\nint apply(uint64_t t, const float *in, float *out, size_t n, void *u) {\n"
+                         "    for (size_t i = 0; i < 2 * n; ++i) out[i] = in[i];\n    return 0;\n}\n")
+    r = subprocess.run([CLI, "-i", wav, "-o", out, "-w", "1024", "--freq-kernel", src, "--devices", "0,0"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "rocoder_hip" in r.stderr
+
+
 def test_cli_default_window_start_duration_rotate(tmp_path):
     x = np.stack([onp.synth_input(c, 44100 * 3) for c in range(2)])
     wav, out = str(tmp_path / "in.wav"), str(tmp_path / "out.wav")
