@@ -608,9 +608,12 @@ __global__ __launch_bounds__(128, 3) void hopw2_kernel(const HopParams p) {
 size_t hopw_lds_bytes() { return sizeof(float2) * (size_t)HOPW_LDS_FLOAT2; }
 
 // N = 4096, fused path, default hanning window (HopParams::hann_rot set: [2][64][4]).
+#ifndef RC_HOPW_PAD
+#define RC_HOPW_PAD 0  // tuning builds: extra LDS bytes per workgroup (caps the waves per SIMD)
+#endif
 hipError_t launch_hopw(const HopParams &p, hipStream_t s) {
     const dim3 grid(p.runs_per_channel * p.n_channels), block(64);
-    const size_t lds = sizeof(float2) * (size_t)HOPW_LDS_FLOAT2;
+    const size_t lds = sizeof(float2) * (size_t)HOPW_LDS_FLOAT2 + RC_HOPW_PAD;
     if (p.pitch == 1) hipLaunchKernelGGL((hopw_kernel<true>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((hopw_kernel<false>), grid, block, lds, s, p);
     return hipGetLastError();
