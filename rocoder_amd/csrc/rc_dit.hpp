@@ -318,4 +318,33 @@ constexpr double HANN_KAPPA = -0.25 / 16384.0;
 __device__ constexpr HannK HANN_W14K = make_hann_k(0.5 * HANN_KAPPA, 16384, 32);
 
 }  // namespace
+
+// ---- decimating stores with the pitch known at compile time (F[t] = O[t * pitch], src/resampler.rs:3-18) ----------
+// A thread owns samples a = a00 + ROW * q + e of the hop (q = register pair, e = 0 / 1, a00 = (g0 % PC) + 2 t, ROW = 2 T
+// samples per register row). With r0 = a00 % PC and d0 = a00 / PC, sample (q, e) is kept iff r0 == (PC - (ROW q + e) % PC)
+// % PC =: c, and then lands at d0 + (c + ROW q + e) / PC - a constant per (q, e). So the whole index arithmetic of a hop
+// is PC selects (byte offset 4 d0 for the lanes of residue class c, an out-of-range offset for the others: the raw
+// buffer store drops them) and every store takes one of those PC registers plus a constant scalar offset.
+template <int PC>
+struct PitchOffsets {
+    uint32_t off[PC];
+};
+constexpr uint32_t PITCH_DROP = 0x80000000u;  // beyond the 1 GiB window of the buffer resource, no wrap with the constants
+template <int PC>
+__device__ __forceinline__ PitchOffsets<PC> pitch_offsets(uint32_t a00) {
+    const uint32_t d0 = a00 / (uint32_t)PC, r0 = a00 - d0 * (uint32_t)PC;
+    PitchOffsets<PC> o;
+#pragma unroll
+    for (int c = 0; c < PC; ++c) o.off[c] = r0 == (uint32_t)c ? 4u * d0 : PITCH_DROP;
+    return o;
+}
+template <int PC, int ROW>
+__device__ __forceinline__ void pitch_store_pair(const __amdgpu_buffer_rsrc_t rsrc, const PitchOffsets<PC> &o, const int q,
+                                                 const float ox, const float oy) {
+    const int ax = ROW * q, ay = ROW * q + 1;
+    const int cx = (PC - ax % PC) % PC, cy = (PC - ay % PC) % PC;
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ox), rsrc, o.off[cx], 4 * ((cx + ax) / PC), 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(oy), rsrc, o.off[cy], 4 * ((cy + ay) / PC), 0);
+}
+
 }  // namespace rc

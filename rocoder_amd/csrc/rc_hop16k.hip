@@ -461,8 +461,10 @@ __device__ __forceinline__ void wave_fence() {
 __device__ __forceinline__ float band_gain(const HopParams &p, uint32_t f) {
     return (f - p.band_lo) <= p.band_span ? p.band_gin : p.band_gout;
 }
-template <bool PITCH1, bool BAND = false>
+// PITCHC: 1 = pitch 1, 2 / 3 = that pitch at compile time (pitch_store_pair), 0 = any pitch > 1 from HopParams
+template <int PITCHC, bool BAND = false>
 __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
+    constexpr bool PITCH1 = PITCHC == 1;
     constexpr int LOG2N = 14, m = 13, M = 1 << m, H = M, T = 256, P = 32, PH = 16;
     constexpr int RES = 512, REG = HOP4_REG;
     constexpr int SCR = HOP4_XBUF + 8;
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
     GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
     const unsigned lane2 = 2u * (unsigned)tid;
     GV2 wtab = (GV2)p.wtab;
-    const uint32_t pitch = PITCH1 ? 1u : p.pitch;
+    const uint32_t pitch = PITCHC ? (uint32_t)PITCHC : p.pitch;
 
     // ---- who am I in each layout. Everything below is a few integer operations on tid; it is recomputed
     // from an opaque copy right before each exchange instead of living in ~20 VGPRs across the whole hop
@@ -642,6 +644,18 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(((unsigned long long)dhi << 32) | dlo), 0, 0x40000000, 0x00020000);  // raw buffer, 1 GiB window
+            if constexpr (PITCHC > 1) {
+                const PitchOffsets<PITCHC> po = pitch_offsets<PITCHC>(kr + 2u * (uint32_t)t2);
+#pragma unroll
+                for (int q = 0; q < PH; ++q) {
+                    const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
+                                   __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
+                    const v2f o = (head[q] + tail[q]) * er;
+                    const float ox = o.x, oy = o.y;
+                    pitch_store_pair<PITCHC, 2 * T>(rsrc, po, q, ox, oy);
+                }
+                return;
+            }
             constexpr uint32_t DROP = 0xFFFFFFFCu;
             const uint32_t a00 = kr + 2u * (uint32_t)t2;
             const uint32_t d0 = a00 / pitch;
@@ -1052,6 +1066,9 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
 
 }  // namespace
 
+#ifndef RC_PITCHC
+#define RC_PITCHC 1  // pitch 2 and 3 run instantiations with the pitch at compile time (0: the runtime-pitch kernel, for A/B)
+#endif
 // N = 16384, fused path: default hanning window -> hop4_kernel (optionally with the band mask in its pair stage),
 // caller-supplied window -> hop2_kernel's table variant. The test-hook library (RC_TEST_HOOKS) can also run the
 // previous generation (hop3_kernel, rc_hop16k_prev.hip) and hop2_kernel's computed-window variant for A/B runs.
@@ -1070,10 +1087,12 @@ hipError_t launch_hop16k(const HopParams &p, hipStream_t s) {
     if (hann) {
         const size_t lds4 = sizeof(float2) * (size_t)HOP4_LDS_FLOAT2;
         if (p.band_on) {
-            if (p.pitch == 1) hipLaunchKernelGGL((hop4_kernel<true, true>), grid, block, lds4, s, p);
-            else hipLaunchKernelGGL((hop4_kernel<false, true>), grid, block, lds4, s, p);
-        } else if (p.pitch == 1) hipLaunchKernelGGL((hop4_kernel<true>), grid, block, lds4, s, p);
-        else hipLaunchKernelGGL((hop4_kernel<false>), grid, block, lds4, s, p);
+            if (p.pitch == 1) hipLaunchKernelGGL((hop4_kernel<1, true>), grid, block, lds4, s, p);
+            else hipLaunchKernelGGL((hop4_kernel<0, true>), grid, block, lds4, s, p);
+        } else if (p.pitch == 1) hipLaunchKernelGGL((hop4_kernel<1>), grid, block, lds4, s, p);
+        else if (p.pitch == 2 && RC_PITCHC) hipLaunchKernelGGL((hop4_kernel<2>), grid, block, lds4, s, p);
+        else if (p.pitch == 3 && RC_PITCHC) hipLaunchKernelGGL((hop4_kernel<3>), grid, block, lds4, s, p);
+        else hipLaunchKernelGGL((hop4_kernel<0>), grid, block, lds4, s, p);
     } else {
         const size_t lds2 = sizeof(float2) * (size_t)HOP2_LDS_FLOAT2;
         if (p.pitch == 1) hipLaunchKernelGGL((hop2_kernel<true, false>), grid, block, lds2, s, p);

@@ -157,12 +157,13 @@ __device__ __forceinline__ void hopw_middle(v2f (&va)[16], v2f (&vb)[16], const 
 
 // Epilogue: synthesis window (times -1/(4N)), overlap-add with the carried tail, store. cbW.. = this thread's window /
 // envelope rotations (cos, sin of beta(2 t), beta(2 t + 1)); t = the thread's index in the hop, 2 T samples per row
-template <bool PITCH1, int T>
+template <int PITCHC, int T>
 __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, const int64_t k, const bool emit, const int t,
                                               v2f (&y)[32], v2f (&tail)[16], const v2f cbW, const v2f sbW, v2f cbE,
                                               v2f sbE, const HannK32 &WK, const HannK32 &E, const float half_kappa,
                                               const uint32_t pitch) {
     constexpr int P = 32, PH = 16, H = T * P;
+    constexpr bool PITCH1 = PITCHC == 1;
     const v2f half2 = {0.5f, 0.5f};
     const unsigned lane2 = 2u * (unsigned)t;
     const v2f half2k = {half_kappa, half_kappa};
@@ -199,6 +200,17 @@ __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, cons
             const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 (void *)(((unsigned long long)dhi << 32) | dlo), 0, 0x40000000, 0x00020000);
+            if constexpr (PITCHC > 1) {  // the pitch at compile time: rc_dit.hpp, pitch_store_pair
+                const PitchOffsets<PITCHC> po = pitch_offsets<PITCHC>(kr + 2u * (uint32_t)t);
+#pragma unroll
+                for (int q = 0; q < PH; ++q) {
+                    const v2f er = __builtin_elementwise_fma(v2f{E.s[q], E.s[q]}, sbE,
+                                   __builtin_elementwise_fma(v2f{E.c[q], E.c[q]}, cbE, halfa));
+                    const v2f o = (y[q] + tail[q]) * er;
+                    const float ox = o.x, oy = o.y;
+                    pitch_store_pair<PITCHC, 2 * T>(rsrc, po, q, ox, oy);
+                }
+            } else {
             constexpr uint32_t DROP = 0xFFFFFFFCu;
             const uint32_t a00 = kr + 2u * (uint32_t)t;
             const uint32_t d0 = a00 / pitch;
@@ -219,13 +231,14 @@ __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, cons
                     d4 += 4u;
                 }
             }
+            }
         }
     }
 #pragma unroll
     for (int q = 0; q < PH; ++q) tail[q] = y[q + PH];
 }
 
-template <bool PITCH1>
+template <int PITCHC>  // 1: pitch 1; 2 / 3: that pitch at compile time; 0: any pitch > 1 from HopParams
 __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
     constexpr int LOG2N = 12, m = 11, T = 64, P = 32, PH = 16, RES = 128;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
     GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
     GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
     const unsigned lane2 = 2u * (unsigned)tid;
-    const uint32_t pitch = PITCH1 ? 1u : p.pitch;
+    const uint32_t pitch = PITCHC ? (uint32_t)PITCHC : p.pitch;
     {   // tables, once per run
         GV2 wt = (GV2)p.wtab;  // exp(-2 pi i k / M), k < M / 2
         GV2 rt = (GV2)p.rtab;  // exp(-2 pi i j / N), j <= M / 4
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
 
         {
             const int t = lane();
-            hopw_epilogue<PITCH1, T>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[HW_TH + 2 * t]), to_v(lds[HW_TH + 2 * t + 1]),
+            hopw_epilogue<PITCHC, T>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[HW_TH + 2 * t]), to_v(lds[HW_TH + 2 * t + 1]),
                                      to_v(lds[HW_TH + 128 + 2 * t]), to_v(lds[HW_TH + 128 + 2 * t + 1]), HANN_W12K, HANN_E12,
                                      (float)(0.5 * HANN_KAPPA12), pitch);
         }
@@ -417,7 +430,7 @@ __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
 //   (lane = P1..P3, P9..P11), F3 stages 8..11 on two sets of 16 (thread tau = 2 lane + wave holds residues tau and
 //   256 - tau; thread 0: residues 0 and 128); I1 stages 0..3, I2 stages 4..6 on registers Q4..Q8, I3 stages 7..11 on
 //   registers Q7..Q11 (thread = Q0..Q6).
-template <bool PITCH1>
+template <int PITCHC>  // 1: pitch 1; 2 / 3: that pitch at compile time; 0: any pitch > 1 from HopParams
 __global__ __launch_bounds__(128, 3) void hopw2_kernel(const HopParams p) {
     constexpr int LOG2N = 13, m = 12, T = 128, P = 32, PH = 16, RES = 256, HALF = H2_BUF / 2;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -432,7 +445,7 @@ __global__ __launch_bounds__(128, 3) void hopw2_kernel(const HopParams p) {
     GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
     GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
     const unsigned lane2 = 2u * (unsigned)tid;
-    const uint32_t pitch = PITCH1 ? 1u : p.pitch;
+    const uint32_t pitch = PITCHC ? (uint32_t)PITCHC : p.pitch;
     {   // tables, once per run
         GV2 wt = (GV2)p.wtab;  // exp(-2 pi i k / M), k < M / 2
         GV2 rt = (GV2)p.rtab;  // exp(-2 pi i j / N), j <= M / 4
@@ -596,7 +609,7 @@ __global__ __launch_bounds__(128, 3) void hopw2_kernel(const HopParams p) {
         dit_stages<32, m, 7, 11, 7, true, true>(y, to_v(lds[H2_TA + thread()]));
         {
             const int t = thread();
-            hopw_epilogue<PITCH1, T>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[H2_TH + 2 * t]), to_v(lds[H2_TH + 2 * t + 1]),
+            hopw_epilogue<PITCHC, T>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[H2_TH + 2 * t]), to_v(lds[H2_TH + 2 * t + 1]),
                                      to_v(lds[H2_TH + 256 + 2 * t]), to_v(lds[H2_TH + 256 + 2 * t + 1]), HANN_W13K, HANN_E13,
                                      (float)(0.5 * HANN_KAPPA13), pitch);
         }
@@ -614,8 +627,10 @@ size_t hopw_lds_bytes() { return sizeof(float2) * (size_t)HOPW_LDS_FLOAT2; }
 hipError_t launch_hopw(const HopParams &p, hipStream_t s) {
     const dim3 grid(p.runs_per_channel * p.n_channels), block(64);
     const size_t lds = sizeof(float2) * (size_t)HOPW_LDS_FLOAT2 + RC_HOPW_PAD;
-    if (p.pitch == 1) hipLaunchKernelGGL((hopw_kernel<true>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((hopw_kernel<false>), grid, block, lds, s, p);
+    if (p.pitch == 1) hipLaunchKernelGGL((hopw_kernel<1>), grid, block, lds, s, p);
+    else if (p.pitch == 2) hipLaunchKernelGGL((hopw_kernel<2>), grid, block, lds, s, p);
+    else if (p.pitch == 3) hipLaunchKernelGGL((hopw_kernel<3>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((hopw_kernel<0>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
@@ -623,8 +638,10 @@ hipError_t launch_hopw(const HopParams &p, hipStream_t s) {
 hipError_t launch_hopw2(const HopParams &p, hipStream_t s) {
     const dim3 grid(p.runs_per_channel * p.n_channels), block(128);
     const size_t lds = sizeof(float2) * (size_t)HOPW2_LDS_FLOAT2;
-    if (p.pitch == 1) hipLaunchKernelGGL((hopw2_kernel<true>), grid, block, lds, s, p);
-    else hipLaunchKernelGGL((hopw2_kernel<false>), grid, block, lds, s, p);
+    if (p.pitch == 1) hipLaunchKernelGGL((hopw2_kernel<1>), grid, block, lds, s, p);
+    else if (p.pitch == 2) hipLaunchKernelGGL((hopw2_kernel<2>), grid, block, lds, s, p);
+    else if (p.pitch == 3) hipLaunchKernelGGL((hopw2_kernel<3>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((hopw2_kernel<0>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
