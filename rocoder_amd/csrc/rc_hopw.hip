@@ -54,6 +54,19 @@ __device__ constexpr HannK32 HANN_E13 = make_hann_w(HANN_ENV_AMP, 4096, 16, 256)
 constexpr double HANN_KAPPA13 = -0.25 / 8192.0;
 __device__ constexpr HannK32 HANN_W13K = make_hann_w(0.5 * HANN_KAPPA13, 8192, 32, 256);
 
+// N = 2048 (hopw11_kernel: 64 threads x 16 points, sample i = 128 q + 2 t + e)
+__device__ constexpr HannK32 HANN_W11 = make_hann_w(0.5, 2048, 16, 128);
+__device__ constexpr HannK32 HANN_E11 = make_hann_w(HANN_ENV_AMP, 1024, 8, 128);
+constexpr double HANN_KAPPA11 = -0.25 / 2048.0;
+__device__ constexpr HannK32 HANN_W11K = make_hann_w(0.5 * HANN_KAPPA11, 2048, 16, 128);
+constexpr int H1_BUF = 552;                       // hopw11: exchange buffer (548 used)
+constexpr int H1_TA = H1_BUF;                     // [65] W_1024^r
+constexpr int H1_TR = H1_TA + 72;                 // [65] W_2048^r (r = 64: lane 0's second residue, as i W)
+constexpr int H1_TB = H1_TR + 72;                 // [8] W_128^l
+constexpr int H1_TC = H1_TB + 8;                  // [8] W_64^l
+constexpr int H1_TH = H1_TC + 8;                  // [256] window / envelope rotations
+constexpr int HOPW11_LDS_FLOAT2 = H1_TH + 256;    // 7 744 B
+
 constexpr int H2_BUF = 2304;                      // hopw2: exchange buffer (2297 used by E1; a wave's own half: 1152)
 constexpr int H2_TA = H2_BUF;                     // [128] W_4096^r
 constexpr int H2_TR = H2_TA + 128;                // [129] W_8192^r, r <= 128 (r = 128: thread 0's second residue, as i W)
@@ -73,9 +86,10 @@ __device__ __forceinline__ void wfence() {
 // ---- pieces shared by the one-wave (N = 4096) and two-wave (N = 8192) kernels -------------------------------------
 // F1: register brev5(q) := z[q * T + t] * window, stages 0..4. Stage 0 pairs registers brev5(q) and brev5(q + 16) =
 // brev5(q) + 1: a +- b with a = x_q w_q and b = x_{q+16} w_{q+16} is one multiply and two FMAs
-template <int T, int m>
-__device__ __forceinline__ void hopw_f1(GF src, unsigned lane2, v2f cb, v2f sb, const HannK32 &W, v2f (&v)[32]) {
-    constexpr int P = 32;
+template <int T, int m, int P = 32>
+__device__ __forceinline__ void hopw_f1(GF src, unsigned lane2, v2f cb, v2f sb, const HannK32 &W, v2f (&v)[P]) {
+    constexpr int LP = P == 32 ? 5 : 4, HP = P / 2;
+    static_assert(P == 32 || P == 16, "points per lane");
     const v2f half2 = {0.5f, 0.5f};
     float xr0[P], xr1[P];
 #pragma unroll
@@ -84,16 +98,16 @@ __device__ __forceinline__ void hopw_f1(GF src, unsigned lane2, v2f cb, v2f sb, 
         xr1[q] = (src + 2 * T * q)[lane2 + 1];
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < HP; ++q) {
         const v2f wl = __builtin_elementwise_fma(v2f{W.s[q], W.s[q]}, sb,
                        __builtin_elementwise_fma(v2f{W.c[q], W.c[q]}, cb, half2));
-        const v2f wh = __builtin_elementwise_fma(v2f{W.s[q + 16], W.s[q + 16]}, sb,
-                       __builtin_elementwise_fma(v2f{W.c[q + 16], W.c[q + 16]}, cb, half2));
-        const v2f a = v2f{xr0[q], xr1[q]} * wl, xh = v2f{xr0[q + 16], xr1[q + 16]};
-        v[2 * brev_c(q, 4)] = __builtin_elementwise_fma(xh, wh, a);
-        v[2 * brev_c(q, 4) + 1] = __builtin_elementwise_fma(-xh, wh, a);
+        const v2f wh = __builtin_elementwise_fma(v2f{W.s[q + HP], W.s[q + HP]}, sb,
+                       __builtin_elementwise_fma(v2f{W.c[q + HP], W.c[q + HP]}, cb, half2));
+        const v2f a = v2f{xr0[q], xr1[q]} * wl, xh = v2f{xr0[q + HP], xr1[q + HP]};
+        v[2 * brev_c(q, LP - 1)] = __builtin_elementwise_fma(xh, wh, a);
+        v[2 * brev_c(q, LP - 1) + 1] = __builtin_elementwise_fma(-xh, wh, a);
     }
-    dit_stages<32, m, 1, 4, 0, false, false>(v);
+    dit_stages<P, m, 1, LP - 1, 0, false, false>(v);
 }
 
 // The middle stage in registers: pair (A[q], B[15 - q]) = bins (r + RES q, M - that), M = 16 RES. Thread 0 owns the
@@ -101,68 +115,70 @@ __device__ __forceinline__ void hopw_f1(GF src, unsigned lane2, v2f cb, v2f sb, 
 // the same 16 slots compute 16 of them (slots 0..7 on residue 0 with bin 0 as slot 0, slots 8..15 on residue RES / 2
 // through a second twiddle base wrh / hash counter) and bin M / 2 is one extra pair (hop4_kernel).
 // wrl = W_N^r, wrh = the same (thread 0: i W_N^(RES / 2)); W_N^(RES q) = W_32^q at both sizes.
-template <int LOG2N, int RES>
-__device__ __forceinline__ void hopw_middle(v2f (&va)[16], v2f (&vb)[16], const bool is0, const uint32_t r,
+template <int LOG2N, int RES, int NS = 16>
+__device__ __forceinline__ void hopw_middle(v2f (&va)[NS], v2f (&vb)[NS], const bool is0, const uint32_t r,
                                             const float2 wrl, const float2 wrh, const PhaseKey &key) {
-    static_assert((1 << LOG2N) == 32 * RES, "N = 32 RES");
-    v2f s8 = va[8];
+    static_assert((1 << LOG2N) == 2 * NS * RES, "N = 2 NS RES");
+    constexpr int h = NS / 2;  // (NS = 16 registers per set at N = 4096 / 8192, 8 at N = 2048: read 16 / 8 / 15 below as NS / h / NS - 1)
+    v2f s8 = va[h];
     {
         const v2f va0 = va[0];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const v2f a = va[8 + i], b0 = vb[i], b1 = vb[8 + i];
-            const v2f nx = i < 7 ? va[9 + i] : va0;
-            va[8 + i] = vsel(is0, b0, a);
+        for (int i = 0; i < h; ++i) {
+            const v2f a = va[h + i], b0 = vb[i], b1 = vb[h + i];
+            const v2f nx = i < h - 1 ? va[h + 1 + i] : va0;
+            va[h + i] = vsel(is0, b0, a);
             vb[i] = vsel(is0, b1, b0);
-            vb[8 + i] = vsel(is0, nx, b1);
+            vb[h + i] = vsel(is0, nx, b1);
         }
     }
     {
         const uint32_t x0 = r * key.mul + key.k0;
         const uint32_t dx = (uint32_t)RES * key.mul;
-        const uint32_t x0h = x0 - (is0 ? (uint32_t)(8 * RES - RES / 2) * key.mul : 0u);  // thread 0: bins RES/2 + RES (q - 8)
+        const uint32_t x0h = x0 - (is0 ? (uint32_t)(h * RES - RES / 2) * key.mul : 0u);  // thread 0: bins RES/2 + RES (q - h)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float2 wr = q < 8 ? wrl : wrh;
+        for (int q = 0; q < NS; ++q) {
+            const float2 wr = q < h ? wrl : wrh;
             const v2f wrv = to_v(wr);
-            const v2f wq = q == 0 ? wrv : (q == 8 ? v2f{wr.y, -wr.x}
-                           : vcmul(wrv, v2f{W32_RE[q & 15], W32_IM[q & 15]}));  // W_N^(RES q) = W_32^q
+            constexpr int WS = 16 / NS;  // W_N^(RES q) = W_(2 NS)^q = W_32^(q WS)
+            const v2f wq = q == 0 ? wrv : (q == h ? v2f{wr.y, -wr.x}
+                           : vcmul(wrv, v2f{W32_RE[(q * WS) & 15], W32_IM[(q * WS) & 15]}));
             v2f VA, VB;
             if (q == 0)
-                pair_regs_pk4<LOG2N, true>(va[q], vb[15 - q], wq, x0, key, VA, VB, is0);
+                pair_regs_pk4<LOG2N, true>(va[q], vb[NS - 1 - q], wq, x0, key, VA, VB, is0);
             else
-                pair_regs_pk4<LOG2N>(va[q], vb[15 - q], wq, (q < 8 ? x0 : x0h) + (uint32_t)q * dx, key, VA, VB);
+                pair_regs_pk4<LOG2N>(va[q], vb[NS - 1 - q], wq, (q < h ? x0 : x0h) + (uint32_t)q * dx, key, VA, VB);
             va[q] = VA;
-            vb[15 - q] = VB;
+            vb[NS - 1 - q] = VB;
         }
     }
     {   // bin M / 2 pairs with itself: exp(-2 pi i (M/2) / N) = -i; then un-deal thread 0's registers
         v2f V8, V8b;
-        pair_regs_pk4<LOG2N>(s8, s8, v2f{0.0f, -1.0f}, 8u * (uint32_t)RES * key.mul + key.k0, key, V8, V8b);
-        v2f na[8], nb0[8], nb1[8];
+        pair_regs_pk4<LOG2N>(s8, s8, v2f{0.0f, -1.0f}, (uint32_t)(h * RES) * key.mul + key.k0, key, V8, V8b);
+        v2f na[h], nb0[h], nb1[h];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            na[i] = vsel(is0, i == 0 ? V8 : vb[7 + i], va[8 + i]);
-            nb0[i] = vsel(is0, va[8 + i], vb[i]);
-            nb1[i] = vsel(is0, vb[i], vb[8 + i]);
+        for (int i = 0; i < h; ++i) {
+            na[i] = vsel(is0, i == 0 ? V8 : vb[h - 1 + i], va[h + i]);
+            nb0[i] = vsel(is0, va[h + i], vb[i]);
+            nb1[i] = vsel(is0, vb[i], vb[h + i]);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            va[8 + i] = na[i];
+        for (int i = 0; i < h; ++i) {
+            va[h + i] = na[i];
             vb[i] = nb0[i];
-            vb[8 + i] = nb1[i];
+            vb[h + i] = nb1[i];
         }
     }
 }
 
 // Epilogue: synthesis window (times -1/(4N)), overlap-add with the carried tail, store. cbW.. = this thread's window /
 // envelope rotations (cos, sin of beta(2 t), beta(2 t + 1)); t = the thread's index in the hop, 2 T samples per row
-template <int PITCHC, int T>
+template <int PITCHC, int T, int P = 32>
 __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, const int64_t k, const bool emit, const int t,
-                                              v2f (&y)[32], v2f (&tail)[16], const v2f cbW, const v2f sbW, v2f cbE,
+                                              v2f (&y)[P], v2f (&tail)[P / 2], const v2f cbW, const v2f sbW, v2f cbE,
                                               v2f sbE, const HannK32 &WK, const HannK32 &E, const float half_kappa,
                                               const uint32_t pitch) {
-    constexpr int P = 32, PH = 16, H = T * P;
+    constexpr int PH = P / 2, H = T * P;
     constexpr bool PITCH1 = PITCHC == 1;
     const v2f half2 = {0.5f, 0.5f};
     const unsigned lane2 = 2u * (unsigned)t;
@@ -420,6 +436,186 @@ __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
 }
 
 
+// ---- N = 2048: hopw11_kernel - one wave per hop with 16 points per lane (M = 1024) ------------------------------
+// hopw_kernel's structure with passes of (4, 3, 3) / (3, 3, 4) stages: F1 stages 0..3 on the 16 registers (P0..P3),
+// F2 stages 4..6 on registers P3..P6 (lane = P0..P2, P7..P9), F3 stages 7..9 on two sets of 8 registers (lane tau holds
+// residues tau and 128 - tau); I1 stages 0..2 on the sets, I2 stages 3..5 on registers Q3..Q6, I3 stages 6..9 on
+// registers Q6..Q9 (lane = Q0..Q5). Exchange rounds: P3, P6 = the set, Q3 = the set, Q6; 8 stores + 8 loads per round
+// through a buffer of 548 float2. tests/dev/proto_w11.py found and checks the weights. ~100 VGPRs and 7.6 KB of LDS per
+// wave: four waves per SIMD.
+#ifndef RC_HOPW11_WPS
+#define RC_HOPW11_WPS 3  // register budget of three waves per SIMD: the allocator takes 112 VGPRs (four still fit; with the budget of four it takes 94 and the kernel is 6 % slower)
+#endif
+template <int PITCHC>
+__global__ __launch_bounds__(64, RC_HOPW11_WPS) void hopw11_kernel(const HopParams p) {
+    constexpr int LOG2N = 11, m = 10, T = 64, P = 16, PH = 8, RES = 128, NS = 8;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int tid = threadIdx.x;
+    const uint32_t run = blockIdx.x % p.runs_per_channel;
+    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
+    int64_t k_end = k_begin + p.run_len;
+    if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
+    if (k_begin >= k_end) return;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
+    const unsigned lane2 = 2u * (unsigned)tid;
+    const uint32_t pitch = PITCHC ? (uint32_t)PITCHC : p.pitch;
+    {   // tables, once per run
+        GV2 wt = (GV2)p.wtab;  // exp(-2 pi i k / M), k < M / 2
+        GV2 rt = (GV2)p.rtab;  // exp(-2 pi i j / N), j <= M / 4
+        lds[H1_TA + tid] = ldg2(wt + tid);
+        lds[H1_TR + tid] = ldg2(rt + tid);
+        if (tid == 0) {
+            lds[H1_TA + 64] = ldg2(wt + 64);
+            const float2 w64 = ldg2(rt + 64);            // lane 0's second residue: W_N^(64 - 512) = i W_N^64
+            lds[H1_TR + 64] = make_float2(-w64.y, w64.x);
+        }
+        if (tid < 8) {
+            lds[H1_TB + tid] = ldg2(wt + 8 * tid);        // W_128^l
+            lds[H1_TC + tid] = ldg2(wt + 16 * tid);       // W_64^l
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float2 a = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid);
+            const float2 b = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid + 1);
+            lds[H1_TH + 128 * i + 2 * tid] = make_float2(a.x, b.x);
+            lds[H1_TH + 128 * i + 2 * tid + 1] = make_float2(a.y, b.y);
+        }
+        __syncthreads();
+    }
+    auto lane = [&]() {
+        int t = tid;
+        opaque(t);
+        return t;
+    };
+    v2f tail[PH];
+#pragma unroll
+    for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
+    const bool is0 = tid == 0;
+
+    for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
+        const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+        v2f v[P];
+        hopw_f1<T, m, P>(hop_src(p, xc, xt, k), lane2, to_v(lds[H1_TH + 2 * tid]), to_v(lds[H1_TH + 2 * tid + 1]), HANN_W11, v);
+        // ---- E1: registers P0..P3 -> P3..P6, round = P3. Weights: P9 1, P8 2, P7 4, P6 8, P0 16, P1 33, P2 72, P4 137,
+        // P5 274 (lane t: P4 = t5 ... P9 = t0)
+        v2f w2[P];
+        int l2;  // F2 lane identity: (P0, P1, P2) = l2 & 7, P7 = bit 3, P8 = bit 4, P9 = bit 5
+        wfence();
+        {
+            const int t = lane();
+            const int b1s = 137 * ((t >> 5) & 1) + 274 * ((t >> 4) & 1) + 8 * ((t >> 3) & 1) + 4 * ((t >> 2) & 1) +
+                            2 * ((t >> 1) & 1) + (t & 1);
+            l2 = t;
+            const int b1l = 16 * (t & 1) + 33 * ((t >> 1) & 1) + 72 * ((t >> 2) & 1) + 4 * ((t >> 3) & 1) +
+                            2 * ((t >> 4) & 1) + ((t >> 5) & 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)  // register 8 h + r: (P0, P1, P2) = r
+                    lds[b1s + 16 * (r & 1) + 33 * ((r >> 1) & 1) + 72 * ((r >> 2) & 1)] = to_f2(v[8 * h + r]);
+                wfence();
+#pragma unroll
+                for (int sg = 0; sg < 8; ++sg)  // register j = h | sg << 1: (P4, P5, P6) = sg
+                    w2[h | (sg << 1)] = to_v(lds[b1l + 137 * (sg & 1) + 274 * ((sg >> 1) & 1) + 8 * ((sg >> 2) & 1)]);
+                wfence();
+            }
+        }
+        dit_stages<16, m, 4, 6, 3, false, true>(w2, to_v(lds[H1_TB + (l2 & 7)]));
+        // ---- E2: registers P3..P6 -> sets of P7..P9, round = P6 = the set. Weights: P0..P5 1..32, P7 72, P8 136, P9 272
+        v2f va[NS], vb[NS];
+        wfence();
+        {
+            const int t = lane();
+            const int b2s = (t & 7) + 72 * ((t >> 3) & 1) + 136 * ((t >> 4) & 1) + 272 * ((t >> 5) & 1);
+            const int tb = (64 - t) & 63;  // low residue bits of 128 - tau (tau = 0: residue 64)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) lds[b2s + 8 * kk] = to_f2(w2[kk | (h << 3)]);  // (P3, P4, P5) = kk
+                wfence();
+                const int bl = h ? tb : t;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const v2f x = to_v(lds[bl + 72 * (q & 1) + 136 * ((q >> 1) & 1) + 272 * ((q >> 2) & 1)]);
+                    if (h) vb[q] = x;
+                    else va[q] = x;
+                }
+                wfence();
+            }
+        }
+        const int r = lane();  // residue of set A (set B: RES - r; lane 0: RES / 2)
+        {
+            const v2f wa = to_v(lds[H1_TA + r]);     // W_M^r
+            const v2f k8 = {W32_RE[4], W32_IM[4]};
+            v2f wb = vcmul(v2f{wa.x, -wa.y}, k8);    // W_M^(RES - r) = W_8 conj(W_M^r)
+            if (is0) wb = v2f{W32_RE[2], W32_IM[2]};  // lane 0: W_M^64 = W_16
+            dit_stages<8, m, 7, 9, 7, false, true>(va, wa);
+            dit_stages<8, m, 7, 9, 7, false, true>(vb, wb);
+        }
+        hopw_middle<LOG2N, RES, NS>(va, vb, is0, (uint32_t)r, lds[H1_TR + r], lds[is0 ? H1_TR + 64 : H1_TR + r], key);
+        // ---- inverse: I1 in registers (register index = brev3(q) = Q0..Q2)
+        v2f pa[NS], pb[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            pa[brev_c(q, 3)] = va[q];
+            pb[brev_c(q, 3)] = vb[q];
+        }
+        dit_stages<8, m, 0, 2, 0, true, false>(pa);
+        dit_stages<8, m, 0, 2, 0, true, false>(pb);
+        // ---- E3: sets of Q0..Q2 -> registers Q3..Q6, round = Q3 = the set. Weights: Q9 1, Q8 2, Q7 4, Q6 8, Q5 16, Q4 32
+        // (= the residue's low six bits as they stand), Q0 65, Q1 136, Q2 272
+        int l5;  // I2 lane identity: (Q0, Q1, Q2) = l5 & 7, Q7 = bit 3, Q8 = bit 4, Q9 = bit 5
+        wfence();
+        {
+            const int t = lane();
+            const int tb = (64 - t) & 63;
+            l5 = t;
+            const int b3l = 65 * (t & 1) + 136 * ((t >> 1) & 1) + 272 * ((t >> 2) & 1) + 4 * ((t >> 3) & 1) +
+                            2 * ((t >> 4) & 1) + ((t >> 5) & 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int bs = h ? tb : t;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    lds[bs + 65 * (q & 1) + 136 * ((q >> 1) & 1) + 272 * ((q >> 2) & 1)] = to_f2(h ? pb[q] : pa[q]);
+                wfence();
+#pragma unroll
+                for (int sg = 0; sg < 8; ++sg)  // register k = h | sg << 1: (Q4, Q5, Q6) = sg
+                    v[h | (sg << 1)] = to_v(lds[b3l + 32 * (sg & 1) + 16 * ((sg >> 1) & 1) + 8 * ((sg >> 2) & 1)]);
+                wfence();
+            }
+        }
+        dit_stages<16, m, 3, 5, 3, true, true>(v, to_v(lds[H1_TC + (l5 & 7)]));
+        // ---- E4: registers Q3..Q6 -> Q6..Q9, round = Q6. Weights: Q0..Q5 1..32, Q7 72, Q8 136, Q9 272
+        v2f y[P];
+        wfence();
+        {
+            const int t = lane();
+            const int b4s = (t & 7) + 72 * ((t >> 3) & 1) + 136 * ((t >> 4) & 1) + 272 * ((t >> 5) & 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) lds[b4s + 8 * kk] = to_f2(v[kk | (h << 3)]);  // (Q3, Q4, Q5) = kk
+                wfence();
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr)  // register (Q7, Q8, Q9) = rr, Q6 = h
+                    y[h | (rr << 1)] = to_v(lds[t + 72 * (rr & 1) + 136 * ((rr >> 1) & 1) + 272 * ((rr >> 2) & 1)]);
+                wfence();
+            }
+        }
+        dit_stages<16, m, 6, 9, 6, true, true>(y, to_v(lds[H1_TA + lane()]));
+        {
+            const int t = lane();
+            hopw_epilogue<PITCHC, T, P>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[H1_TH + 2 * t]), to_v(lds[H1_TH + 2 * t + 1]),
+                                        to_v(lds[H1_TH + 128 + 2 * t]), to_v(lds[H1_TH + 128 + 2 * t + 1]), HANN_W11K, HANN_E11,
+                                        (float)(0.5 * HANN_KAPPA11), pitch);
+        }
+    }
+}
+
 // ---- N = 8192: hopw2_kernel - TWO WAVES PER HOP (128 threads x 32 complex points, M = 4096) ---------------------
 // hopw_kernel's structure with one more stage (passes of (5, 3, 4) / (4, 3, 5)); tests/dev/proto_w2.py is the index
 // model. The wave is the LOWEST position bit P0 = lowest bin bit = Q11 wherever the data is in bin order: residue r and
@@ -631,6 +827,17 @@ hipError_t launch_hopw(const HopParams &p, hipStream_t s) {
     else if (p.pitch == 2) hipLaunchKernelGGL((hopw_kernel<2>), grid, block, lds, s, p);
     else if (p.pitch == 3) hipLaunchKernelGGL((hopw_kernel<3>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((hopw_kernel<0>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+// N = 2048, fused path, default hanning window (HopParams::hann_rot set: [2][64][4]).
+hipError_t launch_hopw11(const HopParams &p, hipStream_t s) {
+    const dim3 grid(p.runs_per_channel * p.n_channels), block(64);
+    const size_t lds = sizeof(float2) * (size_t)HOPW11_LDS_FLOAT2;
+    if (p.pitch == 1) hipLaunchKernelGGL((hopw11_kernel<1>), grid, block, lds, s, p);
+    else if (p.pitch == 2) hipLaunchKernelGGL((hopw11_kernel<2>), grid, block, lds, s, p);
+    else if (p.pitch == 3) hipLaunchKernelGGL((hopw11_kernel<3>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((hopw11_kernel<0>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 

@@ -1092,16 +1092,17 @@ def test_non_power_of_two_window_refft_device_kernel_and_streaming():
 
 
 @pytest.mark.parametrize("p", [1, 2, 3])
-@pytest.mark.parametrize("N", [4096, 8192])
+@pytest.mark.parametrize("N", [2048, 4096, 8192])
 def test_4096_8192_wave_local_kernels_every_sample_and_ranges(N, p):
-    """hopw_kernel (window 4096, default hanning: one wave per hop, every exchange wave-local) and hopw2_kernel (8192:
-    two waves per hop, the bin-order exchanges wave-local): a mid-size stereo job on every sample against the oracle
+    """hopw_kernel (window 4096, default hanning: one wave per hop, every exchange wave-local), hopw11_kernel (2048: the
+    same with 16 points per lane) and hopw2_kernel (8192: two waves per hop, the bin-order exchanges wave-local): a
+    mid-size stereo job on every sample against the oracle
     (thousands of runs: first-hop recompute at every run start, the end of the stream, thread 0's self-paired bins),
     per-half-window blocks, and bit-equality of every shard plan with the whole job."""
     import torch
 
     ra = _engine_mod()
-    f, L, seed = 8.0, 900_000 * (N // 4096), 0xABCD
+    f, L, seed = 8.0, 900_000 * N // 4096, 0xABCD
     x = np.stack([onp.synth_input(c, L) for c in range(2)])
     xt = torch.from_numpy(x).cuda()
     with ra.Engine(window_len=N, factor=f, pitch_multiple=p, channels=2, seed=seed) as e:
