@@ -70,3 +70,16 @@ int rc_engine_next_window(rc_engine *e, uint32_t c, float *out, size_t cap, size
     *n_out = N;
     return RC_OK;
 }
+
+/* --devices (rc_multi_*): not part of what the TSan run exercises - the CLI only needs the symbols to link */
+size_t rc_offline_output_len(const rc_config *cfg, size_t in_len) { (void)cfg; return in_len; }
+int rc_multi_create(const rc_config *cfg, const int32_t *device_ids, uint32_t n_devices, rc_multi **out) {
+    (void)cfg; (void)device_ids; (void)n_devices; (void)out;
+    return RC_EUNSUPPORTED;
+}
+void rc_multi_destroy(rc_multi *m) { (void)m; }
+int rc_multi_stretch_host(rc_multi *m, const float *const *in, size_t in_len, float *const *out, size_t out_cap,
+                          size_t *out_len) {
+    (void)m; (void)in; (void)in_len; (void)out; (void)out_cap; (void)out_len;
+    return RC_EUNSUPPORTED;
+}
