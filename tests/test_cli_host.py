@@ -127,3 +127,17 @@ def test_wav_reader_survives_truncated_and_garbage_files(tmp_path):
             ch, _rate, frames = (int(v) for v in r.stdout.split())
             assert os.path.getsize(raw) == 4 * ch * frames, (k, r.stdout)
     assert not bad, bad[:5]
+
+
+def test_stub_engine_defines_every_engine_symbol_the_cli_imports(tmp_path):
+    """The TSan target links the CLI against tests/c/stub_engine.c (tools/run_sanitizers.sh): a new engine call in the
+    CLI without its stub breaks that build. Compile both here (no sanitizer, seconds) and compare symbol tables."""
+    obj, so = str(tmp_path / "cli.o"), str(tmp_path / "stub.so")
+    src = os.path.join(ROOT, "rocoder_amd", "csrc", "host", "rocoder_cli.cpp")
+    subprocess.run(["g++", "-std=c++17", "-O0", "-c", src, "-o", obj], check=True, timeout=300)
+    subprocess.run(["gcc", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "stub_engine.c"), "-o", so],
+                   check=True, timeout=120)
+    und = {l.split()[-1] for l in subprocess.run(["nm", "-u", obj], capture_output=True, text=True, check=True).stdout.splitlines()
+           if l.split()[-1].startswith("rc_")}
+    have = {l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout.splitlines()}
+    assert und and und <= have, sorted(und - have)
