@@ -73,6 +73,18 @@ __device__ __forceinline__ void vdit_rot_m(v2f a, v2f b, v2f w, v2f &r, v2f &o) 
     const v2f two = {2.0f, 2.0f};
     o = __builtin_elementwise_fma(a, two, -r);
 }
+//   twiddle -i (CONJ: +i): no multiply at all - the swap and the sign ride on the VOP3P modifiers of two packed adds
+#ifndef RC_ASMROT
+#define RC_ASMROT 1
+#endif
+template <bool CONJ>
+__device__ __forceinline__ void vdit_i(v2f a, v2f b, v2f &r, v2f &o) {
+    v2f p, m;  // p = (a.x + b.y, a.y - b.x) = a - i b ; m = (a.x - b.y, a.y + b.x) = a + i b
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(p) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(m) : "v"(a), "v"(b));
+    r = CONJ ? m : p;
+    o = CONJ ? p : m;
+}
 template <int NREG, int M_LOG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L>
 __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f}) {
     if (RC_ABLATE & 8) return;
@@ -99,7 +111,9 @@ __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], v2f wfine = v2f{1.0f,
                 if (c == 0) {
                     v[q0] = a + b;
                     v[q1] = a - b;
-                } else if (kidx == 8) {  // w b = -i b (forward) / +i b (inverse) = -(b.yx * sgn)
+                } else if (kidx == 8 && RC_ASMROT) {  // w b = -i b (forward) / +i b (inverse)
+                    vdit_i<CONJ>(a, b, v[q0], v[q1]);
+                } else if (kidx == 8) {  // ... = -(b.yx * sgn)
                     const v2f ib = __builtin_shufflevector(b, b, 1, 0) * sgn;
                     v[q0] = a - ib;
                     v[q1] = a + ib;
