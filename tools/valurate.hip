@@ -11,7 +11,7 @@ constexpr int ITER = 4096, UNR = 16;
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k(float *out, float seed) {
+__global__ __launch_bounds__(256) void k(float *out, float seed, float seed2) {
     float a[UNR];
     v2f p[UNR];
     unsigned u[UNR];
@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void k(float *out, float seed) {
     }
     unsigned long long mask = __ballot(threadIdx.x & 1);
     const unsigned vm = (threadIdx.x & 1) ? ~0u : 0u;
+    const v2f sp = {seed, seed2};  // (kernel arguments: an SGPR pair)
     for (int it = 0; it < ITER / 4; ++it) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -49,6 +50,12 @@ __global__ __launch_bounds__(256) void k(float *out, float seed) {
                 if (KIND == 18) asm volatile("v_add_f32 %0, %0, %0" : "+v"(a[i]));
                 if (KIND == 19) asm volatile("v_mul_f32 %0, %0, %0" : "+v"(a[i]));
                 if (KIND == 20) asm volatile("v_pk_fma_f32 %0, %0, %1, %0 op_sel_hi:[1,0,1]" : "+v"(p[i]) : "v"(p[(i + 1) % UNR]));
+                if (KIND == 21) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(p[i]) : "s"(sp));
+                if (KIND == 22) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "s"(sp), "v"(p[(i + 1) % UNR]));
+                if (KIND == 23) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p[i]) : "s"(sp));
+                if (KIND == 24) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(p[i]) : "v"(p[(i + 1) % UNR]), "v"(p[(i + 2) % UNR]), "v"(p[(i + 3) % UNR]));
+                if (KIND == 25) asm volatile("v_pk_fma_f32 %0, %0, %1, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(p[i]) : "v"(p[(i + 1) % UNR]));
+                if (KIND == 26) asm volatile("v_cos_f32 %0, %0\n v_pk_fma_f32 %1, %1, %1, %1" : "+v"(a[i]), "+v"(p[i]));
             }
         }
     }
@@ -64,10 +71,10 @@ void run(const char *name, float *d, int cus, double mhz) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const int wgs = cus * 8;  // 2 workgroups of 4 waves per CU resident x 4 rounds ... (occupancy is not limited: all resident)
-    hipLaunchKernelGGL(k<KIND>, dim3(wgs), dim3(256), 0, 0, d, 1.0f);
+    hipLaunchKernelGGL(k<KIND>, dim3(wgs), dim3(256), 0, 0, d, 1.0f, 0.25f);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k<KIND>, dim3(wgs), dim3(256), 0, 0, d, 1.0f);
+    hipLaunchKernelGGL(k<KIND>, dim3(wgs), dim3(256), 0, 0, d, 1.0f, 0.25f);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -102,6 +109,12 @@ int main() {
         run<11>("v_bfi_b32", d, cus, mhz);
         run<12>("v_pk_add_f32", d, cus, mhz);
         run<20>("v_pk_fma opsel", d, cus, mhz);
+        run<21>("v_pk_fma sgpr", d, cus, mhz);
+        run<22>("v_pk_fma sgpr+2v", d, cus, mhz);
+        run<23>("v_pk_mul sgpr", d, cus, mhz);
+        run<24>("v_pk_fma 3 srcs", d, cus, mhz);
+        run<25>("v_pk_fma opsel+neg", d, cus, mhz);
+        run<26>("v_cos + v_pk_fma", d, cus, mhz);
         run<13>("v_add_u32", d, cus, mhz);
         run<14>("v_lshrrev_b32", d, cus, mhz);
         run<15>("v_and_or_b32", d, cus, mhz);
