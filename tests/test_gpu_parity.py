@@ -498,10 +498,12 @@ def test_streaming_kernel_call_order_is_the_processors():
 
 
 # ------------------------------------------------------------------ streaming seam
-def test_stretcher_windows_match_oracle_streaming():
+@pytest.mark.parametrize("N", [2048, 4096, 8192])
+def test_stretcher_windows_match_oracle_streaming(N):
+    """(the default window at these lengths: the wave-local kernels, launched on ranges of one or two windows)"""
     ra = _engine_mod()
     x = onp.synth_input(0, 50000)
-    w = oc.hanning(2048)
+    w = oc.hanning(N)
     q: "queue.Queue" = queue.Queue()
     s = ra.Stretcher(ra.AudioSpec(1, 44100), q, 4.0, 1.0, 1, w, seed=21)
     o = oc.Stretcher(sample_rate=44100, channels=1, factor=4.0, window=w, seed=21)
