@@ -75,6 +75,9 @@ constexpr int H2_TC = H2_TB + 16;                 // [16] W_128^l
 constexpr int H2_TH = H2_TC + 16;                 // [512] window / envelope rotations: thread t at 2 t (+ 256: envelope)
 constexpr int HOPW2_LDS_FLOAT2 = H2_TH + 512;     // 24 896 B
 
+#ifndef RC_HOPW_NT
+#define RC_HOPW_NT 1  // non-temporal output stores (0: plain write-back stores, for A/B)
+#endif
 #ifndef RC_HOPW_PREFETCH
 #define RC_HOPW_PREFETCH 1  // hopw11_kernel: next hop's loads before the last inverse pass (0: after the stores, for A/B)
 #endif
@@ -216,7 +219,8 @@ __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, cons
                 const v2f er = __builtin_elementwise_fma(v2f{E.s[q], E.s[q]}, sbE,
                                __builtin_elementwise_fma(v2f{E.c[q], E.c[q]}, cbE, halfa));
                 const v2f o = (y[q] + tail[q]) * er;  // (y + tail) * (env * amp), stretcher.rs:97-100
-                __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));
+                if (RC_HOPW_NT) __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));
+                else *(GV2W)(dst + 2 * T * q + lane2) = o;
             }
         } else {
             // F[t] = O[t * pitch] (src/resampler.rs:3-18): branch-free raw buffer stores, a lane that keeps
