@@ -54,6 +54,19 @@ __device__ constexpr HannK32 HANN_E13 = make_hann_w(HANN_ENV_AMP, 4096, 16, 256)
 constexpr double HANN_KAPPA13 = -0.25 / 8192.0;
 __device__ constexpr HannK32 HANN_W13K = make_hann_w(0.5 * HANN_KAPPA13, 8192, 32, 256);
 
+// N = 1024 (hopw10_kernel: two hops per wave, 32 lanes x 16 points each, sample i = 64 q + 2 t + e)
+__device__ constexpr HannK32 HANN_W10 = make_hann_w(0.5, 1024, 16, 64);
+__device__ constexpr HannK32 HANN_E10 = make_hann_w(HANN_ENV_AMP, 512, 8, 64);
+constexpr double HANN_KAPPA10 = -0.25 / 1024.0;
+__device__ constexpr HannK32 HANN_W10K = make_hann_w(0.5 * HANN_KAPPA10, 1024, 16, 64);
+constexpr int H0_HB = 288;                        // hopw10: exchange buffer of ONE half-wave (288 used)
+constexpr int H0_TA = 2 * H0_HB;                  // [33] W_512^r
+constexpr int H0_TR = H0_TA + 40;                 // [33] W_1024^r (r = 32: lane 0's second residue, as i W)
+constexpr int H0_TB = H0_TR + 40;                 // [8] W_64^l
+constexpr int H0_TC = H0_TB + 8;                  // [8] W_32^l
+constexpr int H0_TH = H0_TC + 8;                  // [128] window / envelope rotations: lane t at 2 t (+ 64: envelope)
+constexpr int HOPW10_LDS_FLOAT2 = H0_TH + 128;    // 6 400 B
+
 // N = 2048 (hopw11_kernel: 64 threads x 16 points, sample i = 128 q + 2 t + e)
 __device__ constexpr HannK32 HANN_W11 = make_hann_w(0.5, 2048, 16, 128);
 __device__ constexpr HannK32 HANN_E11 = make_hann_w(HANN_ENV_AMP, 1024, 8, 128);
@@ -188,7 +201,16 @@ __device__ __forceinline__ void hopw_middle(v2f (&va)[NS], v2f (&vb)[NS], const 
 
 // Epilogue: synthesis window (times -1/(4N)), overlap-add with the carried tail, store. cbW.. = this thread's window /
 // envelope rotations (cos, sin of beta(2 t), beta(2 t + 1)); t = the thread's index in the hop, 2 T samples per row
-template <int PITCHC, int T, int P = 32>
+template <int P>
+__device__ __forceinline__ void hopw_window(v2f (&y)[P], const v2f cbW, const v2f sbW, const HannK32 &WK, const float half_kappa) {
+    const v2f half2k = {half_kappa, half_kappa};
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+        y[q] *= __builtin_elementwise_fma(v2f{WK.s[q], WK.s[q]}, sbW,
+                __builtin_elementwise_fma(v2f{WK.c[q], WK.c[q]}, cbW, half2k));
+}
+// (WINDOWED: the caller has applied hopw_window already - hopw10_kernel, which fetches the other half-wave's tail between)
+template <int PITCHC, int T, int P = 32, bool WINDOWED = false>
 __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, const int64_t k, const bool emit, const int t,
                                               v2f (&y)[P], v2f (&tail)[P / 2], const v2f cbW, const v2f sbW, v2f cbE,
                                               v2f sbE, const HannK32 &WK, const HannK32 &E, const float half_kappa,
@@ -197,11 +219,7 @@ __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, cons
     constexpr bool PITCH1 = PITCHC == 1;
     const v2f half2 = {0.5f, 0.5f};
     const unsigned lane2 = 2u * (unsigned)t;
-    const v2f half2k = {half_kappa, half_kappa};
-#pragma unroll
-    for (int q = 0; q < P; ++q)
-        y[q] *= __builtin_elementwise_fma(v2f{WK.s[q], WK.s[q]}, sbW,
-                __builtin_elementwise_fma(v2f{WK.c[q], WK.c[q]}, cbW, half2k));
+    if (!WINDOWED) hopw_window<P>(y, cbW, sbW, WK, half_kappa);
     if (emit) {
         const v2f amp2 = {p.amp, p.amp};
         // env[i] * amp = amp/2 + c_q (amp cb) + s_q (amp sb): the amplitude rides on the per-thread rotation
@@ -640,6 +658,211 @@ __global__ __launch_bounds__(64, RC_HOPW11_WPS) void hopw11_kernel(const HopPara
     }
 }
 
+// ---- N = 1024: hopw10_kernel - TWO HOPS PER WAVE (M = 512 = 32 lanes x 16 points per hop) ---------------------------
+// Lanes 0-31 run hop kk, lanes 32-63 hop kk + 1 of the same run, each half-wave with hopw11_kernel's structure minus one
+// stage: passes (4, 2, 3) / (3, 2, 4), two sets of 8 registers around the pair stage (lane tau of a half holds residues
+// tau and 64 - tau), exchange rounds P3, P5 = the set, Q3 = the set, Q5 through 288 float2 per half (ds_write_b64 banks
+// in 16-lane groups, ds_read_b64 in 32-lane groups = one half; tests/dev/proto_w10.py searched and checks the weights).
+// The hop index, the phase key, the source pointer and the store offsets are per lane. Overlap-add across the halves:
+// the upper half's head takes the lower half's tail of the same iteration, the lower half's head the upper half's tail of
+// the iteration before - one v_permlane32_swap per register moves both.
+__device__ __forceinline__ GF hop_src_lane(const HopParams &p, GF xc, GF xt, int64_t k) {
+    const int64_t off = (k >= p.tail_hop_first) ? (k * (int64_t)p.step - p.tail_origin) : (k * (int64_t)p.step - p.in_origin);
+    return ((k >= p.tail_hop_first) ? xt : xc) + off;
+}
+template <int PITCHC>
+__global__ __launch_bounds__(64, 3) void hopw10_kernel(const HopParams p) {
+    constexpr int LOG2N = 10, m = 9, T = 32, P = 16, PH = 8, RES = 64, NS = 8;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int tid = threadIdx.x;
+    const uint32_t run = blockIdx.x % p.runs_per_channel;
+    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
+    int64_t k_end = k_begin + p.run_len;
+    if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
+    if (k_begin >= k_end) return;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
+    const uint32_t pitch = PITCHC ? (uint32_t)PITCHC : p.pitch;
+    {   // tables, once per run
+        GV2 wt = (GV2)p.wtab;  // exp(-2 pi i k / M), k < M / 2
+        GV2 rt = (GV2)p.rtab;  // exp(-2 pi i j / N), j <= M / 4
+        if (tid < 33) {
+            lds[H0_TA + tid] = ldg2(wt + tid);
+            const float2 w = ldg2(rt + tid);
+            lds[H0_TR + tid] = tid == 32 ? make_float2(-w.y, w.x) : w;  // [32]: W_N^(32 - 256) = i W_N^32
+        }
+        if (tid < 8) {
+            lds[H0_TB + tid] = ldg2(wt + 8 * tid);    // W_64^l
+            lds[H0_TC + tid] = ldg2(wt + 16 * tid);   // W_32^l
+        }
+        if (tid < 32) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {  // hann_rot: [part][64 threads][4]; the 32 lanes of a hop are threads 0..31
+                const float2 a = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid);
+                const float2 b = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid + 1);
+                lds[H0_TH + 64 * i + 2 * tid] = make_float2(a.x, b.x);
+                lds[H0_TH + 64 * i + 2 * tid + 1] = make_float2(a.y, b.y);
+            }
+        }
+        __syncthreads();
+    }
+    auto lane = [&]() {
+        int t = tid;
+        opaque(t);
+        return t;
+    };
+    v2f tail[PH];  // the windowed second half of this lane's last hop
+#pragma unroll
+    for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
+    const bool is0 = (tid & 31) == 0;
+    const int64_t k_first = k_begin > 0 ? k_begin - 1 : k_begin;
+
+    for (int64_t kk = k_first; kk < k_end; kk += 2) {
+        const int hf = lane() >> 5;
+        const int64_t k = kk + hf;                          // this lane's hop
+        const bool valid = k < k_end;
+        const int64_t kc = valid ? k : k_end - 1;           // (an odd tail: the upper half recomputes the last hop, unused)
+        const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, kc);
+        float2 *own = lds + H0_HB * hf;
+        v2f v[P];
+        {
+            const int tl = tid & 31;
+            float xr0[P], xr1[P];
+            hopw_load<T, P>(hop_src_lane(p, xc, xt, kc), 2u * (unsigned)tl, xr0, xr1);
+            hopw_f1x<T, m, P>(xr0, xr1, to_v(lds[H0_TH + 2 * tl]), to_v(lds[H0_TH + 2 * tl + 1]), HANN_W10, v);
+        }
+        // ---- E1: registers P0..P3 -> P3..P6, round = P3. Weights: P8 1, P7 2, P6 4, P5 8, P0 16, P1 36, P2 72, P4 140
+        // (lane t of the half: P4 = t4 ... P8 = t0)
+        v2f w2[P];
+        int l2;  // F2 lane identity: (P0, P1, P2) = l2 & 7, P7 = bit 3, P8 = bit 4
+        wfence();
+        {
+            const int t = lane() & 31;
+            const int b1s = 140 * ((t >> 4) & 1) + 8 * ((t >> 3) & 1) + 4 * ((t >> 2) & 1) + 2 * ((t >> 1) & 1) + (t & 1);
+            l2 = t;
+            const int b1l = 16 * (t & 1) + 36 * ((t >> 1) & 1) + 72 * ((t >> 2) & 1) + 2 * ((t >> 3) & 1) + ((t >> 4) & 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)  // register 8 h + r: (P0, P1, P2) = r
+                    own[b1s + 16 * (r & 1) + 36 * ((r >> 1) & 1) + 72 * ((r >> 2) & 1)] = to_f2(v[8 * h + r]);
+                wfence();
+#pragma unroll
+                for (int sg = 0; sg < 8; ++sg)  // register j = h | sg << 1: (P4, P5, P6) = sg
+                    w2[h | (sg << 1)] = to_v(own[b1l + 140 * (sg & 1) + 8 * ((sg >> 1) & 1) + 4 * ((sg >> 2) & 1)]);
+                wfence();
+            }
+        }
+        dit_stages<16, m, 4, 5, 3, false, true>(w2, to_v(lds[H0_TB + (l2 & 7)]));
+        // ---- E2: registers P3..P6 -> sets of P6..P8, round = P5 = the set. Weights: P0..P4 1..16, P6 32, P7 72, P8 136
+        v2f va[NS], vb[NS];
+        wfence();
+        {
+            const int t = lane() & 31;
+            const int b2s = (t & 7) + 72 * ((t >> 3) & 1) + 136 * ((t >> 4) & 1);
+            const int tb = (32 - t) & 31;  // low residue bits of 64 - tau (tau = 0: residue 32)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int kq = 0; kq < 8; ++kq)  // registers with P5 = h: (P3, P4, P6) = kq
+                    own[b2s + 8 * (kq & 1) + 16 * ((kq >> 1) & 1) + 32 * ((kq >> 2) & 1)] = to_f2(w2[(kq & 3) | (h << 2) | ((kq >> 2) << 3)]);
+                wfence();
+                const int bl = h ? tb : t;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const v2f x = to_v(own[bl + 32 * (q & 1) + 72 * ((q >> 1) & 1) + 136 * ((q >> 2) & 1)]);
+                    if (h) vb[q] = x;
+                    else va[q] = x;
+                }
+                wfence();
+            }
+        }
+        const int r = lane() & 31;  // residue of set A (set B: RES - r; lane 0 of the half: RES / 2)
+        {
+            const v2f wa = to_v(lds[H0_TA + r]);     // W_M^r
+            const v2f k8 = {W32_RE[4], W32_IM[4]};
+            v2f wb = vcmul(v2f{wa.x, -wa.y}, k8);    // W_M^(RES - r) = W_8 conj(W_M^r)
+            if (is0) wb = v2f{W32_RE[2], W32_IM[2]};  // lane 0: W_M^32 = W_16
+            dit_stages<8, m, 6, 8, 6, false, true>(va, wa);
+            dit_stages<8, m, 6, 8, 6, false, true>(vb, wb);
+        }
+        hopw_middle<LOG2N, RES, NS>(va, vb, is0, (uint32_t)r, lds[H0_TR + r], lds[is0 ? H0_TR + 32 : H0_TR + r], key);
+        // ---- inverse: I1 in registers (register index = brev3(q) = Q0..Q2)
+        v2f pa[NS], pb[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            pa[brev_c(q, 3)] = va[q];
+            pb[brev_c(q, 3)] = vb[q];
+        }
+        dit_stages<8, m, 0, 2, 0, true, false>(pa);
+        dit_stages<8, m, 0, 2, 0, true, false>(pb);
+        // ---- E3: sets of Q0..Q2 -> registers Q3..Q6, round = Q3 = the set. Weights: Q8 1, Q7 2, Q6 4, Q5 8, Q4 16 (= the
+        // residue's low five bits as they stand), Q0 36, Q1 72, Q2 144
+        int l5;  // I2 lane identity: (Q0, Q1, Q2) = l5 & 7, Q7 = bit 3, Q8 = bit 4
+        wfence();
+        {
+            const int t = lane() & 31;
+            const int tb = (32 - t) & 31;
+            l5 = t;
+            const int b3l = 36 * (t & 1) + 72 * ((t >> 1) & 1) + 144 * ((t >> 2) & 1) + 2 * ((t >> 3) & 1) + ((t >> 4) & 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int bs = h ? tb : t;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    own[bs + 36 * (q & 1) + 72 * ((q >> 1) & 1) + 144 * ((q >> 2) & 1)] = to_f2(h ? pb[q] : pa[q]);
+                wfence();
+#pragma unroll
+                for (int sg = 0; sg < 8; ++sg)  // register k = h | sg << 1: (Q4, Q5, Q6) = sg
+                    v[h | (sg << 1)] = to_v(own[b3l + 16 * (sg & 1) + 8 * ((sg >> 1) & 1) + 4 * ((sg >> 2) & 1)]);
+                wfence();
+            }
+        }
+        dit_stages<16, m, 3, 4, 3, true, true>(v, to_v(lds[H0_TC + (l5 & 7)]));
+        // ---- E4: registers Q3..Q6 -> Q5..Q8, round = Q5. Weights: Q0..Q4 1..16, Q7 40, Q6 72, Q8 144
+        v2f y[P];
+        wfence();
+        {
+            const int t = lane() & 31;
+            const int b4s = (t & 7) + 40 * ((t >> 3) & 1) + 144 * ((t >> 4) & 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int kq = 0; kq < 8; ++kq)  // registers with Q5 = h: (Q3, Q4, Q6) = kq
+                    own[b4s + 8 * (kq & 1) + 16 * ((kq >> 1) & 1) + 72 * ((kq >> 2) & 1)] = to_f2(v[(kq & 3) | (h << 2) | ((kq >> 2) << 3)]);
+                wfence();
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr)  // register (Q6, Q7, Q8) = rr, Q5 = h
+                    y[h | (rr << 1)] = to_v(own[t + 72 * (rr & 1) + 40 * ((rr >> 1) & 1) + 144 * ((rr >> 2) & 1)]);
+                wfence();
+            }
+        }
+        dit_stages<16, m, 5, 8, 5, true, true>(y, to_v(lds[H0_TA + (lane() & 31)]));
+        {
+            const int t = lane(), tl = t & 31, up = t >> 5;
+            hopw_window<P>(y, to_v(lds[H0_TH + 2 * tl]), to_v(lds[H0_TH + 2 * tl + 1]), HANN_W10K, (float)(0.5 * HANN_KAPPA10));
+            // the tail this lane's head overlaps: lower half <- upper half's tail of the iteration before (carried in
+            // `tail`), upper half <- lower half's tail of this iteration. v_permlane32_swap(a, b): a = (a.lo, b.lo),
+            // b = (a.hi, b.hi) over the two half-waves
+            v2f tin[PH];
+#pragma unroll
+            for (int q = 0; q < PH; ++q) {
+                float ax = tail[q].x, bx = y[PH + q].x, ay = tail[q].y, by = y[PH + q].y;
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(ax), "+v"(bx));
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(ay), "+v"(by));
+                tin[q] = up ? v2f{ax, ay} : v2f{bx, by};
+                tail[q] = y[PH + q];
+            }
+            // stores: the iteration's base is hop kk (uniform); the upper half's samples lie H = 512 further on
+            hopw_epilogue<PITCHC, T, P, true>(p, outc, kk, valid && k >= k_begin, tl + 256 * up, y, tin,
+                                              v2f{0.f, 0.f}, v2f{0.f, 0.f}, to_v(lds[H0_TH + 64 + 2 * tl]),
+                                              to_v(lds[H0_TH + 64 + 2 * tl + 1]), HANN_W10K, HANN_E10, 0.0f, pitch);
+        }
+    }
+}
+
 // ---- N = 8192: hopw2_kernel - TWO WAVES PER HOP (128 threads x 32 complex points, M = 4096) ---------------------
 // hopw_kernel's structure with one more stage (passes of (5, 3, 4) / (4, 3, 5)); tests/dev/proto_w2.py is the index
 // model. The wave is the LOWEST position bit P0 = lowest bin bit = Q11 wherever the data is in bin order: residue r and
@@ -851,6 +1074,17 @@ hipError_t launch_hopw(const HopParams &p, hipStream_t s) {
     else if (p.pitch == 2) hipLaunchKernelGGL((hopw_kernel<2>), grid, block, lds, s, p);
     else if (p.pitch == 3) hipLaunchKernelGGL((hopw_kernel<3>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((hopw_kernel<0>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+// N = 1024, fused path, default hanning window (HopParams::hann_rot set: [2][64][4]).
+hipError_t launch_hopw10(const HopParams &p, hipStream_t s) {
+    const dim3 grid(p.runs_per_channel * p.n_channels), block(64);
+    const size_t lds = sizeof(float2) * (size_t)HOPW10_LDS_FLOAT2;
+    if (p.pitch == 1) hipLaunchKernelGGL((hopw10_kernel<1>), grid, block, lds, s, p);
+    else if (p.pitch == 2) hipLaunchKernelGGL((hopw10_kernel<2>), grid, block, lds, s, p);
+    else if (p.pitch == 3) hipLaunchKernelGGL((hopw10_kernel<3>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((hopw10_kernel<0>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 
