@@ -23,7 +23,7 @@
 // No MFMA: this is an FFT/SFU/LDS-bound path, not a contraction.
 #include "rc_passes.hpp"
 #ifndef RC_HOPW
-#define RC_HOPW 15  // default window: bit 0 N = 4096 runs hopw_kernel, bit 1 N = 8192 hopw2_kernel, bit 2 N = 2048 hopw11_kernel, bit 3 N = 1024 hopw10_kernel (0: generic, for A/B)
+#define RC_HOPW 31  // default window: bit 0 N = 4096 runs hopw_kernel, bit 1 N = 8192 hopw2_kernel, bit 2 N = 2048 hopw11_kernel, bit 3 N = 1024 hopw10_kernel, bit 4 N = 512 hopw9_kernel (0: generic, for A/B)
 #endif
 #include "rc_dit.hpp"  // (the constexpr sine / cosine of the computed-window constants)
 
@@ -406,6 +406,7 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
             else if (LOG2N == 13 && (RC_HOPW & 2) && p.hann_rot) return launch_hopw2(p, s);  // two waves per hop
             else if (LOG2N == 11 && (RC_HOPW & 4) && p.hann_rot) return launch_hopw11(p, s);  // one wave, 16 points per lane
             else if (LOG2N == 10 && (RC_HOPW & 8) && p.hann_rot) return launch_hopw10(p, s);  // two hops per wave
+            else if (LOG2N == 9 && (RC_HOPW & 16) && p.hann_rot) return launch_hopw9(p, s);   // two hops per wave, 8 points per lane
             else if (p.hann_rot && p.pitch == 1) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true, true>), grid, block, lds, s, p);
             else if (p.hann_rot) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, false, true>), grid, block, lds, s, p);
             else if (p.pitch == 1) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true>), grid, block, lds, s, p);
@@ -438,6 +439,7 @@ int hop_resident_workgroups(int log2n, bool default_window) {
 #endif
     if (log2n == 11 && (RC_HOPW & 4)) return RC_HOPW11_RES;  // hopw11_kernel: one wave each
     if (log2n == 10 && (RC_HOPW & 8)) return 16;  // hopw10_kernel: one wave (two hops at a time) each, four per SIMD
+    if (log2n == 9 && (RC_HOPW & 16)) return 16;  // hopw9_kernel
     return 0;
 }
 

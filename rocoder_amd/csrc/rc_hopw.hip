@@ -54,6 +54,19 @@ __device__ constexpr HannK32 HANN_E13 = make_hann_w(HANN_ENV_AMP, 4096, 16, 256)
 constexpr double HANN_KAPPA13 = -0.25 / 8192.0;
 __device__ constexpr HannK32 HANN_W13K = make_hann_w(0.5 * HANN_KAPPA13, 8192, 32, 256);
 
+// N = 512 (hopw9_kernel: two hops per wave, 32 lanes x 8 points each, sample i = 64 q + 2 t + e)
+__device__ constexpr HannK32 HANN_W9 = make_hann_w(0.5, 512, 8, 64);
+__device__ constexpr HannK32 HANN_E9 = make_hann_w(HANN_ENV_AMP, 256, 4, 64);
+constexpr double HANN_KAPPA9 = -0.25 / 512.0;
+__device__ constexpr HannK32 HANN_W9K = make_hann_w(0.5 * HANN_KAPPA9, 512, 8, 64);
+constexpr int H9_HB = 288;                        // hopw9: exchange buffer of ONE half-wave (284 used)
+constexpr int H9_TA = 2 * H9_HB;                  // [33] W_256^r
+constexpr int H9_TR = H9_TA + 40;                 // [33] W_512^r (r = 32: lane 0's second residue, as i W)
+constexpr int H9_TB = H9_TR + 40;                 // [8] W_64^l
+constexpr int H9_TC = H9_TB + 8;                  // [4] W_32^l
+constexpr int H9_TH = H9_TC + 8;                  // [128] window / envelope rotations
+constexpr int HOPW9_LDS_FLOAT2 = H9_TH + 128;     // 6 400 B
+
 // N = 1024 (hopw10_kernel: two hops per wave, 32 lanes x 16 points each, sample i = 64 q + 2 t + e)
 __device__ constexpr HannK32 HANN_W10 = make_hann_w(0.5, 1024, 16, 64);
 __device__ constexpr HannK32 HANN_E10 = make_hann_w(HANN_ENV_AMP, 512, 8, 64);
@@ -116,8 +129,8 @@ __device__ __forceinline__ void hopw_load(GF src, unsigned lane2, float (&xr0)[P
 }
 template <int T, int m, int P = 32>
 __device__ __forceinline__ void hopw_f1x(const float (&xr0)[P], const float (&xr1)[P], v2f cb, v2f sb, const HannK32 &W, v2f (&v)[P]) {
-    constexpr int LP = P == 32 ? 5 : 4, HP = P / 2;
-    static_assert(P == 32 || P == 16, "points per lane");
+    constexpr int LP = P == 32 ? 5 : (P == 16 ? 4 : 3), HP = P / 2;
+    static_assert(P == 32 || P == 16 || P == 8, "points per lane");
     const v2f half2 = {0.5f, 0.5f};
 #pragma unroll
     for (int q = 0; q < HP; ++q) {
@@ -863,6 +876,176 @@ __global__ __launch_bounds__(64, 3) void hopw10_kernel(const HopParams p) {
     }
 }
 
+// ---- N = 512: hopw9_kernel - two hops per wave, 8 points per lane (M = 256 = 32 lanes x 8) ----------------------------
+// hopw10_kernel's arrangement with passes of (3, 3, 2) / (2, 3, 3) stages: every pass uses all three register bits, so an
+// exchange is ONE round of 8 stores + 8 loads per lane through 284 float2 per half (tests/dev/proto_w9.py); two sets of 4
+// registers around the pair stage (lane tau of a half holds residues tau and 64 - tau).
+template <int PITCHC>
+__global__ __launch_bounds__(64, 4) void hopw9_kernel(const HopParams p) {
+    constexpr int LOG2N = 9, m = 8, T = 32, P = 8, PH = 4, RES = 64, NS = 4;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int tid = threadIdx.x;
+    const uint32_t run = blockIdx.x % p.runs_per_channel;
+    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
+    int64_t k_end = k_begin + p.run_len;
+    if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
+    if (k_begin >= k_end) return;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
+    const uint32_t pitch = PITCHC ? (uint32_t)PITCHC : p.pitch;
+    {   // tables, once per run
+        GV2 wt = (GV2)p.wtab;  // exp(-2 pi i k / M), k < M / 2
+        GV2 rt = (GV2)p.rtab;  // exp(-2 pi i j / N), j <= M / 4
+        if (tid < 33) {
+            lds[H9_TA + tid] = ldg2(wt + tid);
+            const float2 w = ldg2(rt + tid);
+            lds[H9_TR + tid] = tid == 32 ? make_float2(-w.y, w.x) : w;  // [32]: W_N^(32 - 128) = i W_N^32
+        }
+        if (tid < 8) lds[H9_TB + tid] = ldg2(wt + 4 * tid);   // W_64^l
+        if (tid < 4) lds[H9_TC + tid] = ldg2(wt + 8 * tid);   // W_32^l
+        if (tid < 32) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {  // hann_rot: [part][64 threads][4]; the 32 lanes of a hop are threads 0..31
+                const float2 a = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid);
+                const float2 b = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid + 1);
+                lds[H9_TH + 64 * i + 2 * tid] = make_float2(a.x, b.x);
+                lds[H9_TH + 64 * i + 2 * tid + 1] = make_float2(a.y, b.y);
+            }
+        }
+        __syncthreads();
+    }
+    auto lane = [&]() {
+        int t = tid;
+        opaque(t);
+        return t;
+    };
+    v2f tail[PH];
+#pragma unroll
+    for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
+    const bool is0 = (tid & 31) == 0;
+    const int64_t k_first = k_begin > 0 ? k_begin - 1 : k_begin;
+
+    for (int64_t kk = k_first; kk < k_end; kk += 2) {
+        const int hf = lane() >> 5;
+        const int64_t k = kk + hf;
+        const bool valid = k < k_end;
+        const int64_t kc = valid ? k : k_end - 1;
+        const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, kc);
+        float2 *own = lds + H9_HB * hf;
+        v2f v[P];
+        {
+            const int tl = tid & 31;
+            float xr0[P], xr1[P];
+            hopw_load<T, P>(hop_src_lane(p, xc, xt, kc), 2u * (unsigned)tl, xr0, xr1);
+            hopw_f1x<T, m, P>(xr0, xr1, to_v(lds[H9_TH + 2 * tl]), to_v(lds[H9_TH + 2 * tl + 1]), HANN_W9, v);
+        }
+        // ---- E1: registers P0..P2 -> P3..P5. Weights: P7 1 ... P3 16 (= the lane as it stands), P0 36, P1 72, P2 144
+        v2f w2[P];
+        int l2;  // F2 lane identity: (P0, P1, P2) = l2 & 7, P6 = bit 3, P7 = bit 4
+        wfence();
+        {
+            const int t = lane() & 31;
+            l2 = t;
+            const int b1l = 36 * (t & 7) + 2 * ((t >> 3) & 1) + ((t >> 4) & 1);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) own[t + 36 * r] = to_f2(v[r]);
+            wfence();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w2[j] = to_v(own[b1l + 16 * (j & 1) + 8 * ((j >> 1) & 1) + 4 * ((j >> 2) & 1)]);
+            wfence();
+        }
+        dit_stages<8, m, 3, 5, 3, false, true>(w2, to_v(lds[H9_TB + (l2 & 7)]));
+        // ---- E2: registers P3..P5 -> sets of P6, P7 (set = P5). Weights: P0..P5 1..32, P6 72, P7 136
+        v2f va[NS], vb[NS];
+        wfence();
+        {
+            const int t = lane() & 31;
+            const int b2s = (t & 7) + 72 * ((t >> 3) & 1) + 136 * ((t >> 4) & 1);
+            const int tb = ((32 - t) & 31) + 32;  // 64 - tau (tau = 0: residue 32): its low five bits, set bit on
+#pragma unroll
+            for (int j = 0; j < 8; ++j) own[b2s + 8 * j] = to_f2(w2[j]);
+            wfence();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                va[q] = to_v(own[t + 72 * (q & 1) + 136 * ((q >> 1) & 1)]);
+                vb[q] = to_v(own[tb + 72 * (q & 1) + 136 * ((q >> 1) & 1)]);
+            }
+            wfence();
+        }
+        const int r = lane() & 31;
+        {
+            const v2f wa = to_v(lds[H9_TA + r]);     // W_M^r
+            v2f wb = v2f{-wa.y, -wa.x};              // W_M^(RES - r) = W_4 conj(W_M^r) = -i conj(W_M^r)
+            if (is0) wb = v2f{W32_RE[4], W32_IM[4]};  // lane 0: W_M^32 = W_8
+            dit_stages<4, m, 6, 7, 6, false, true>(va, wa);
+            dit_stages<4, m, 6, 7, 6, false, true>(vb, wb);
+        }
+        hopw_middle<LOG2N, RES, NS>(va, vb, is0, (uint32_t)r, lds[H9_TR + r], lds[is0 ? H9_TR + 32 : H9_TR + r], key);
+        // ---- inverse: I1 in registers (register index = brev2(q) = Q0, Q1)
+        v2f pa[NS], pb[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+            pa[brev_c(q, 2)] = va[q];
+            pb[brev_c(q, 2)] = vb[q];
+        }
+        dit_stages<4, m, 0, 1, 0, true, false>(pa);
+        dit_stages<4, m, 0, 1, 0, true, false>(pb);
+        // ---- E3: sets of Q0, Q1 -> registers Q2..Q4. Weights: Q7 1 ... Q3 16 (= the residue's low five bits), Q2 32 (the
+        // set), Q0 72, Q1 144
+        int l5;  // I2 lane identity: (Q0, Q1) = l5 & 3, Q5 = bit 2, Q6 = bit 3, Q7 = bit 4
+        wfence();
+        {
+            const int t = lane() & 31;
+            const int tb = ((32 - t) & 31) + 32;
+            l5 = t;
+            const int b3l = 72 * (t & 1) + 144 * ((t >> 1) & 1) + 4 * ((t >> 2) & 1) + 2 * ((t >> 3) & 1) + ((t >> 4) & 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                own[t + 72 * (q & 1) + 144 * ((q >> 1) & 1)] = to_f2(pa[q]);
+                own[tb + 72 * (q & 1) + 144 * ((q >> 1) & 1)] = to_f2(pb[q]);
+            }
+            wfence();
+#pragma unroll
+            for (int kq = 0; kq < 8; ++kq)  // register (Q2, Q3, Q4) = kq
+                v[kq] = to_v(own[b3l + 32 * (kq & 1) + 16 * ((kq >> 1) & 1) + 8 * ((kq >> 2) & 1)]);
+            wfence();
+        }
+        dit_stages<8, m, 2, 4, 2, true, true>(v, to_v(lds[H9_TC + (l5 & 3)]));
+        // ---- E4: registers Q2..Q4 -> Q5..Q7. Weights: Q0..Q4 1..16, Q5 36, Q6 72, Q7 140
+        v2f y[P];
+        wfence();
+        {
+            const int t = lane() & 31;
+            const int b4s = (t & 3) + 36 * ((t >> 2) & 1) + 72 * ((t >> 3) & 1) + 140 * ((t >> 4) & 1);
+#pragma unroll
+            for (int kq = 0; kq < 8; ++kq) own[b4s + 4 * kq] = to_f2(v[kq]);
+            wfence();
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) y[rr] = to_v(own[t + 36 * (rr & 1) + 72 * ((rr >> 1) & 1) + 140 * ((rr >> 2) & 1)]);
+            wfence();
+        }
+        dit_stages<8, m, 5, 7, 5, true, true>(y, to_v(lds[H9_TA + (lane() & 31)]));
+        {
+            const int t = lane(), tl = t & 31, up = t >> 5;
+            hopw_window<P>(y, to_v(lds[H9_TH + 2 * tl]), to_v(lds[H9_TH + 2 * tl + 1]), HANN_W9K, (float)(0.5 * HANN_KAPPA9));
+            v2f tin[PH];  // (hopw10_kernel: the other half-wave's tail)
+#pragma unroll
+            for (int q = 0; q < PH; ++q) {
+                float ax = tail[q].x, bx = y[PH + q].x, ay = tail[q].y, by = y[PH + q].y;
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(ax), "+v"(bx));
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(ay), "+v"(by));
+                tin[q] = up ? v2f{ax, ay} : v2f{bx, by};
+                tail[q] = y[PH + q];
+            }
+            hopw_epilogue<PITCHC, T, P, true>(p, outc, kk, valid && k >= k_begin, tl + 128 * up, y, tin,
+                                              v2f{0.f, 0.f}, v2f{0.f, 0.f}, to_v(lds[H9_TH + 64 + 2 * tl]),
+                                              to_v(lds[H9_TH + 64 + 2 * tl + 1]), HANN_W9K, HANN_E9, 0.0f, pitch);
+        }
+    }
+}
+
 // ---- N = 8192: hopw2_kernel - TWO WAVES PER HOP (128 threads x 32 complex points, M = 4096) ---------------------
 // hopw_kernel's structure with one more stage (passes of (5, 3, 4) / (4, 3, 5)); tests/dev/proto_w2.py is the index
 // model. The wave is the LOWEST position bit P0 = lowest bin bit = Q11 wherever the data is in bin order: residue r and
@@ -1074,6 +1257,17 @@ hipError_t launch_hopw(const HopParams &p, hipStream_t s) {
     else if (p.pitch == 2) hipLaunchKernelGGL((hopw_kernel<2>), grid, block, lds, s, p);
     else if (p.pitch == 3) hipLaunchKernelGGL((hopw_kernel<3>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((hopw_kernel<0>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+// N = 512, fused path, default hanning window (HopParams::hann_rot set: [2][64][4]).
+hipError_t launch_hopw9(const HopParams &p, hipStream_t s) {
+    const dim3 grid(p.runs_per_channel * p.n_channels), block(64);
+    const size_t lds = sizeof(float2) * (size_t)HOPW9_LDS_FLOAT2;
+    if (p.pitch == 1) hipLaunchKernelGGL((hopw9_kernel<1>), grid, block, lds, s, p);
+    else if (p.pitch == 2) hipLaunchKernelGGL((hopw9_kernel<2>), grid, block, lds, s, p);
+    else if (p.pitch == 3) hipLaunchKernelGGL((hopw9_kernel<3>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((hopw9_kernel<0>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 

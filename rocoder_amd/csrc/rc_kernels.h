@@ -172,6 +172,8 @@ hipError_t launch_hop16k(const HopParams &p, hipStream_t s);
 hipError_t launch_hop16k_prev(const HopParams &p, hipStream_t s);
 // N = 4096, fused path, default window: one wave per hop (rc_hopw.hip)
 hipError_t launch_hopw(const HopParams &p, hipStream_t s);
+// N = 512 with the default window: two hops per wave, 8 points per lane (rc_hopw.hip)
+hipError_t launch_hopw9(const HopParams &p, hipStream_t s);
 // N = 1024 with the default window: two hops per wave (rc_hopw.hip)
 hipError_t launch_hopw10(const HopParams &p, hipStream_t s);
 // N = 2048 with the default window: one wave per hop, 16 points per lane (rc_hopw.hip)

@@ -498,7 +498,7 @@ def test_streaming_kernel_call_order_is_the_processors():
 
 
 # ------------------------------------------------------------------ streaming seam
-@pytest.mark.parametrize("N", [1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("N", [512, 1024, 2048, 4096, 8192])
 def test_stretcher_windows_match_oracle_streaming(N):
     """(the default window at these lengths: the wave-local kernels, launched on ranges of one or two windows)"""
     ra = _engine_mod()
@@ -1094,7 +1094,7 @@ def test_non_power_of_two_window_refft_device_kernel_and_streaming():
 
 
 @pytest.mark.parametrize("p", [1, 2, 3])
-@pytest.mark.parametrize("N", [1024, 2048, 4096, 8192])
+@pytest.mark.parametrize("N", [512, 1024, 2048, 4096, 8192])
 def test_4096_8192_wave_local_kernels_every_sample_and_ranges(N, p):
     """hopw_kernel (window 4096, default hanning: one wave per hop, every exchange wave-local), hopw11_kernel (2048: the
     same with 16 points per lane) and hopw2_kernel (8192: two waves per hop, the bin-order exchanges wave-local): a
