@@ -683,8 +683,11 @@ __device__ __forceinline__ GF hop_src_lane(const HopParams &p, GF xc, GF xt, int
     const int64_t off = (k >= p.tail_hop_first) ? (k * (int64_t)p.step - p.tail_origin) : (k * (int64_t)p.step - p.in_origin);
     return ((k >= p.tail_hop_first) ? xt : xc) + off;
 }
+#ifndef RC_HOPW10_WPS
+#define RC_HOPW10_WPS 3  // register budget (waves per SIMD) the allocator is given
+#endif
 template <int PITCHC>
-__global__ __launch_bounds__(64, 3) void hopw10_kernel(const HopParams p) {
+__global__ __launch_bounds__(64, RC_HOPW10_WPS) void hopw10_kernel(const HopParams p) {
     constexpr int LOG2N = 10, m = 9, T = 32, P = 16, PH = 8, RES = 64, NS = 8;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
@@ -880,8 +883,11 @@ __global__ __launch_bounds__(64, 3) void hopw10_kernel(const HopParams p) {
 // hopw10_kernel's arrangement with passes of (3, 3, 2) / (2, 3, 3) stages: every pass uses all three register bits, so an
 // exchange is ONE round of 8 stores + 8 loads per lane through 284 float2 per half (tests/dev/proto_w9.py); two sets of 4
 // registers around the pair stage (lane tau of a half holds residues tau and 64 - tau).
+#ifndef RC_HOPW9_WPS
+#define RC_HOPW9_WPS 4  // register budget (waves per SIMD) the allocator is given
+#endif
 template <int PITCHC>
-__global__ __launch_bounds__(64, 4) void hopw9_kernel(const HopParams p) {
+__global__ __launch_bounds__(64, RC_HOPW9_WPS) void hopw9_kernel(const HopParams p) {
     constexpr int LOG2N = 9, m = 8, T = 32, P = 8, PH = 4, RES = 64, NS = 4;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
