@@ -97,6 +97,8 @@ def test_one_hop_golden(goldens):  # ReFFT seam: src/fft.rs:42-74
     # pitch 2 / 3 run kernels with the pitch at compile time, every other pitch the runtime-pitch kernel
     (16384, 300000, 8.0, 2, 2), (16384, 300000, 4.0, 4, 1), (16384, 300000, 2.0, 5, 2), (16384, 200000, 3.0, 7, 1),
     (4096, 100000, 4.0, 4, 2), (4096, 100000, 2.0, 5, 1), (8192, 150000, 4.0, 4, 1), (8192, 150000, 8.0, 7, 2),
+    (512, 30000, 4.0, 4, 2), (512, 30000, 8.0, 2, 1), (1024, 50000, 2.0, 5, 2), (1024, 50001, 8.0, 2, 1), (2048, 70000, 4.0, 4, 1),
+    (512, 7777, 1.0, 1, 3), (1024, 9999, 0.3, 1, 1),
     # speed-up factors below 0.5 (sample_step_len > window_len, README "-f 0.2"): see DESIGN.md §8
     (1024, 60000, 0.2, 1, 2), (16384, 600000, 0.25, 1, 1), (512, 20000, 0.1, 2, 1), (32768, 500000, 0.25, 1, 1),
 ])
