@@ -402,15 +402,32 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
     switch (mode) {
         case MODE_FUSED:
             if constexpr (LOG2N == 14) return launch_hop16k(p, s);  // hop4_kernel / hop2_kernel (rc_hop16k.hip)
-            else if (LOG2N == 12 && (RC_HOPW & 1) && p.hann_rot) return launch_hopw(p, s);  // one wave per hop (rc_hopw.hip)
-            else if (LOG2N == 13 && (RC_HOPW & 2) && p.hann_rot) return launch_hopw2(p, s);  // two waves per hop
-            else if (LOG2N == 11 && (RC_HOPW & 4) && p.hann_rot) return launch_hopw11(p, s);  // one wave, 16 points per lane
-            else if (LOG2N == 10 && (RC_HOPW & 8) && p.hann_rot) return launch_hopw10(p, s);  // two hops per wave
-            else if (LOG2N == 9 && (RC_HOPW & 16) && p.hann_rot) return launch_hopw9(p, s);   // two hops per wave, 8 points per lane
-            else if (p.hann_rot && p.pitch == 1) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true, true>), grid, block, lds, s, p);
-            else if (p.hann_rot) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, false, true>), grid, block, lds, s, p);
-            else if (p.pitch == 1) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true>), grid, block, lds, s, p);
-            else hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, false>), grid, block, lds, s, p);
+            else {
+                // default window at 512 ... 8192: the wave-local kernels (rc_hopw.hip); the generic kernel's
+                // computed-window instantiations then exist for the shorter lengths only
+                constexpr bool WL = (LOG2N == 12 && (RC_HOPW & 1)) || (LOG2N == 13 && (RC_HOPW & 2)) || (LOG2N == 11 && (RC_HOPW & 4)) ||
+                                    (LOG2N == 10 && (RC_HOPW & 8)) || (LOG2N == 9 && (RC_HOPW & 16));
+                if constexpr (WL) {
+                    if (p.hann_rot) {
+                        if constexpr (LOG2N == 12) return launch_hopw(p, s);     // one wave per hop
+                        if constexpr (LOG2N == 13) return launch_hopw2(p, s);    // two waves per hop
+                        if constexpr (LOG2N == 11) return launch_hopw11(p, s);   // one wave, 16 points per lane
+                        if constexpr (LOG2N == 10) return launch_hopw10(p, s);   // two hops per wave
+                        if constexpr (LOG2N == 9) return launch_hopw9(p, s);     // two hops per wave, 8 points per lane
+                    }
+                } else {
+                    if (p.hann_rot && p.pitch == 1) {
+                        hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true, true>), grid, block, lds, s, p);
+                        break;
+                    }
+                    if (p.hann_rot) {
+                        hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, false, true>), grid, block, lds, s, p);
+                        break;
+                    }
+                }
+                if (p.pitch == 1) hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true>), grid, block, lds, s, p);
+                else hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, false>), grid, block, lds, s, p);
+            }
             break;
         case MODE_FORWARD:
             hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FORWARD, true>), grid, block, lds, s, p);
