@@ -55,6 +55,9 @@ __global__ __launch_bounds__(256) void k(float *out, float seed, float seed2) {
                 if (KIND == 23) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p[i]) : "s"(sp));
                 if (KIND == 24) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(p[i]) : "v"(p[(i + 1) % UNR]), "v"(p[(i + 2) % UNR]), "v"(p[(i + 3) % UNR]));
                 if (KIND == 25) asm volatile("v_pk_fma_f32 %0, %0, %1, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(p[i]) : "v"(p[(i + 1) % UNR]));
+                if (KIND == 27) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[(i + 1) % UNR]));
+                if (KIND == 28) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(u[i]), "+v"(u[(i + 1) % UNR]));
+                if (KIND == 29) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(u[i]) : "v"(u[(i + 1) % UNR]));
                 if (KIND == 26) asm volatile("v_cos_f32 %0, %0\n v_pk_fma_f32 %1, %1, %1, %1" : "+v"(a[i]), "+v"(p[i]));
             }
         }
@@ -115,6 +118,9 @@ int main() {
         run<24>("v_pk_fma 3 srcs", d, cus, mhz);
         run<25>("v_pk_fma opsel+neg", d, cus, mhz);
         run<26>("v_cos + v_pk_fma", d, cus, mhz);
+        run<27>("v_permlane32_swap", d, cus, mhz);
+        run<28>("v_permlane16_swap", d, cus, mhz);
+        run<29>("v_mov_dpp quad_perm", d, cus, mhz);
         run<13>("v_add_u32", d, cus, mhz);
         run<14>("v_lshrrev_b32", d, cus, mhz);
         run<15>("v_and_or_b32", d, cus, mhz);
