@@ -15,7 +15,7 @@ worst, ran, t0 = 0.0, 0, time.time()
 while ran < n_cases:
     kind = rng.integers(0, 10)
     if kind < 6:
-        N = int(rng.choice([2048, 4096, 8192, 16384]))
+        N = int(rng.choice([512, 1024, 2048, 4096, 8192, 16384]))
     elif kind < 8:
         N = 1 << int(rng.integers(5, 17))
     else:
