@@ -446,9 +446,6 @@ int hop_workgroups_per_cu(int log2n, bool default_window) {
 
 int hop_resident_workgroups(int log2n, bool default_window) {
     if (!default_window) return 0;
-#ifdef RC_HOPW_RES
-    if (log2n == 12 && (RC_HOPW & 1)) return RC_HOPW_RES;  // tuning builds (with RC_HOPW_PAD)
-#endif
     if (log2n == 12 && (RC_HOPW & 1)) return 12;  // hopw_kernel: one wave each, three per SIMD
     if (log2n == 13 && (RC_HOPW & 2)) return 6;   // hopw2_kernel: two waves each
 #ifndef RC_HOPW11_RES

@@ -101,9 +101,6 @@ constexpr int H2_TC = H2_TB + 16;                 // [16] W_128^l
 constexpr int H2_TH = H2_TC + 16;                 // [512] window / envelope rotations: thread t at 2 t (+ 256: envelope)
 constexpr int HOPW2_LDS_FLOAT2 = H2_TH + 512;     // 24 896 B
 
-#ifndef RC_HOPW_NT
-#define RC_HOPW_NT 1  // non-temporal output stores (0: plain write-back stores, for A/B)
-#endif
 #ifndef RC_HOPW_PREFETCH
 #define RC_HOPW_PREFETCH 1  // hopw11_kernel: next hop's loads before the last inverse pass (0: after the stores, for A/B)
 #endif
@@ -250,8 +247,7 @@ __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, cons
                 const v2f er = __builtin_elementwise_fma(v2f{E.s[q], E.s[q]}, sbE,
                                __builtin_elementwise_fma(v2f{E.c[q], E.c[q]}, cbE, halfa));
                 const v2f o = (y[q] + tail[q]) * er;  // (y + tail) * (env * amp), stretcher.rs:97-100
-                if (RC_HOPW_NT) __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));
-                else *(GV2W)(dst + 2 * T * q + lane2) = o;
+                __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));  // (plain stores: +2 % at 2048 / 8192)
             }
         } else {
             // F[t] = O[t * pitch] (src/resampler.rs:3-18): branch-free raw buffer stores, a lane that keeps
@@ -683,11 +679,8 @@ __device__ __forceinline__ GF hop_src_lane(const HopParams &p, GF xc, GF xt, int
     const int64_t off = (k >= p.tail_hop_first) ? (k * (int64_t)p.step - p.tail_origin) : (k * (int64_t)p.step - p.in_origin);
     return ((k >= p.tail_hop_first) ? xt : xc) + off;
 }
-#ifndef RC_HOPW10_WPS
-#define RC_HOPW10_WPS 3  // register budget (waves per SIMD) the allocator is given
-#endif
 template <int PITCHC>
-__global__ __launch_bounds__(64, RC_HOPW10_WPS) void hopw10_kernel(const HopParams p) {
+__global__ __launch_bounds__(64, 3) void hopw10_kernel(const HopParams p) {
     constexpr int LOG2N = 10, m = 9, T = 32, P = 16, PH = 8, RES = 64, NS = 8;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
@@ -883,11 +876,8 @@ __global__ __launch_bounds__(64, RC_HOPW10_WPS) void hopw10_kernel(const HopPara
 // hopw10_kernel's arrangement with passes of (3, 3, 2) / (2, 3, 3) stages: every pass uses all three register bits, so an
 // exchange is ONE round of 8 stores + 8 loads per lane through 284 float2 per half (tests/dev/proto_w9.py); two sets of 4
 // registers around the pair stage (lane tau of a half holds residues tau and 64 - tau).
-#ifndef RC_HOPW9_WPS
-#define RC_HOPW9_WPS 4  // register budget (waves per SIMD) the allocator is given
-#endif
 template <int PITCHC>
-__global__ __launch_bounds__(64, RC_HOPW9_WPS) void hopw9_kernel(const HopParams p) {
+__global__ __launch_bounds__(64, 4) void hopw9_kernel(const HopParams p) {
     constexpr int LOG2N = 9, m = 8, T = 32, P = 8, PH = 4, RES = 64, NS = 4;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
@@ -1253,12 +1243,9 @@ __global__ __launch_bounds__(128, 3) void hopw2_kernel(const HopParams p) {
 size_t hopw_lds_bytes() { return sizeof(float2) * (size_t)HOPW_LDS_FLOAT2; }
 
 // N = 4096, fused path, default hanning window (HopParams::hann_rot set: [2][64][4]).
-#ifndef RC_HOPW_PAD
-#define RC_HOPW_PAD 0  // tuning builds: extra LDS bytes per workgroup (caps the waves per SIMD)
-#endif
 hipError_t launch_hopw(const HopParams &p, hipStream_t s) {
     const dim3 grid(p.runs_per_channel * p.n_channels), block(64);
-    const size_t lds = sizeof(float2) * (size_t)HOPW_LDS_FLOAT2 + RC_HOPW_PAD;
+    const size_t lds = sizeof(float2) * (size_t)HOPW_LDS_FLOAT2;
     if (p.pitch == 1) hipLaunchKernelGGL((hopw_kernel<1>), grid, block, lds, s, p);
     else if (p.pitch == 2) hipLaunchKernelGGL((hopw_kernel<2>), grid, block, lds, s, p);
     else if (p.pitch == 3) hipLaunchKernelGGL((hopw_kernel<3>), grid, block, lds, s, p);
