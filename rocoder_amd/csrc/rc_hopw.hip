@@ -153,13 +153,14 @@ __device__ __forceinline__ void hopw_f1(GF src, unsigned lane2, v2f cb, v2f sb, 
 // the same 16 slots compute 16 of them (slots 0..7 on residue 0 with bin 0 as slot 0, slots 8..15 on residue RES / 2
 // through a second twiddle base wrh / hash counter) and bin M / 2 is one extra pair (hop4_kernel).
 // wrl = W_N^r, wrh = the same (thread 0: i W_N^(RES / 2)); W_N^(RES q) = W_32^q at both sizes.
+// has0 (wave-uniform): this wave contains thread 0 - the other wave of hopw2_kernel skips the re-deal and the extra pair
 template <int LOG2N, int RES, int NS = 16>
 __device__ __forceinline__ void hopw_middle(v2f (&va)[NS], v2f (&vb)[NS], const bool is0, const uint32_t r,
-                                            const float2 wrl, const float2 wrh, const PhaseKey &key) {
+                                            const float2 wrl, const float2 wrh, const PhaseKey &key, const bool has0 = true) {
     static_assert((1 << LOG2N) == 2 * NS * RES, "N = 2 NS RES");
     constexpr int h = NS / 2;  // (NS = 16 registers per set at N = 4096 / 8192, 8 at N = 2048: read 16 / 8 / 15 below as NS / h / NS - 1)
     v2f s8 = va[h];
-    {
+    if (has0) {
         const v2f va0 = va[0];
 #pragma unroll
         for (int i = 0; i < h; ++i) {
@@ -190,7 +191,7 @@ __device__ __forceinline__ void hopw_middle(v2f (&va)[NS], v2f (&vb)[NS], const 
             vb[NS - 1 - q] = VB;
         }
     }
-    {   // bin M / 2 pairs with itself: exp(-2 pi i (M/2) / N) = -i; then un-deal thread 0's registers
+    if (has0) {  // bin M / 2 pairs with itself: exp(-2 pi i (M/2) / N) = -i; then un-deal thread 0's registers
         v2f V8, V8b;
         pair_regs_pk4<LOG2N>(s8, s8, v2f{0.0f, -1.0f}, (uint32_t)(h * RES) * key.mul + key.k0, key, V8, V8b);
         v2f na[h], nb0[h], nb1[h];
@@ -1170,7 +1171,7 @@ __global__ __launch_bounds__(128, 3) void hopw2_kernel(const HopParams p) {
             dit_stages<16, m, 8, 11, 8, false, true>(va, wa);
             dit_stages<16, m, 8, 11, 8, false, true>(vb, wb);
         }
-        hopw_middle<LOG2N, RES>(va, vb, is0, (uint32_t)r, lds[H2_TR + r], lds[is0 ? H2_TR + 128 : H2_TR + r], key);
+        hopw_middle<LOG2N, RES>(va, vb, is0, (uint32_t)r, lds[H2_TR + r], lds[is0 ? H2_TR + 128 : H2_TR + r], key, tid < 64);
         // ---- inverse: I1 in registers (register index = brev4(q) = Q0..Q3)
         v2f pa[16], pb[16];
 #pragma unroll
