@@ -112,7 +112,10 @@ def test_stretch_matches_oracle(N, L, f, p, ch):
 
 
 @pytest.mark.parametrize("N,L", [(256, 0), (256, 1), (256, 255), (256, 256), (256, 257),
-                                 (1024, 1023), (16384, 16384), (16384, 20001)])
+                                 (1024, 1023), (16384, 16384), (16384, 20001),
+                                 # the wave-local kernels: one hop, two hops, an odd count for the two-hops-per-wave ones
+                                 (512, 0), (512, 1), (512, 512), (512, 513), (512, 700), (1024, 0), (1024, 1), (1024, 1024),
+                                 (1024, 1025), (1024, 1300), (2048, 100), (2048, 2049), (4096, 5000), (8192, 8192), (8192, 9000)])
 def test_edge_lengths(N, L):  # empty / shorter than one window / ragged tails (stretcher.rs:129-132)
     ra = _engine_mod()
     x = onp.synth_input(1, L)[None]
