@@ -228,6 +228,8 @@ struct rc_engine {
     int tune_rounds = 0, tune_min_run = 0, tune_b4_rounds = 0;
     std::vector<float> h_spec, h_spec2;
     bool tail_zeroed = false;
+    bool as_pitch1 = false;  // run_hops is computing O (pitch 1) for the negative-pitch path's resampler
+    DevBuf d_obuf;           // ... into this scratch
     // user-kernel path: a stateful apply() forbids recomputing hops, so the overlap tail is carried
     // on the device and ranges must continue where the previous one ended (or restart at hop 0)
     std::vector<int64_t> kernel_next_hop;
@@ -672,7 +674,41 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
                             rc::hop_workgroups_per_cu(e->log2n, e->d_hann_rot != nullptr) != 0 &&
                             !(e->diag_flags & rc::RC_DIAG_PREV_KERNEL);
     const bool devk = (e->cfg.device_kernel == RC_DK_BAND && !band_fused) || e->cfg.device_kernel == RC_DK_SHIFT;
-    const bool fused = !e->gen && !e->cfg.kernel && !devk && e->log2n <= 14 && e->cfg.pitch_multiple >= 1;
+    const bool pos_pitch = e->cfg.pitch_multiple >= 1 || e->as_pitch1;
+    const bool fused = !e->gen && !e->cfg.kernel && !devk && e->log2n <= 14 && pos_pitch;
+#ifndef RC_NEGFUSED
+#define RC_NEGFUSED 1  // negative pitch multiples: the fused kernels at pitch 1 into scratch + resample_slower_kernel (0: unfused, for A/B)
+#endif
+    if (RC_NEGFUSED && e->cfg.pitch_multiple < 0 && !e->as_pitch1 && !e->gen && !e->cfg.kernel && !devk &&
+        !(e->diag_flags & rc::RC_DIAG_PREV_KERNEL)) {
+        // pitch <= -2 (one hop per window, src/stretcher.rs:47-49): O = the pitch-1 overlap-add of the hop range, computed by
+        // the fused kernels into scratch in pieces of <= 256 MiB, then each window = resample_slower(O_k[0..S))
+        const int64_t piece = std::max<int64_t>(1, (int64_t)(((size_t)256 << 20) / ((size_t)n_channels * H * sizeof(float))));
+        for (int64_t k0 = hop_first; k0 < hop_first + hop_count; k0 += piece) {
+            const int64_t kc = std::min<int64_t>(piece, hop_first + hop_count - k0);
+            if (int rcb = e->d_obuf.reserve((size_t)n_channels * kc * H * sizeof(float))) return rcb;
+            e->as_pitch1 = true;
+            const int rcr = run_hops(e, d_in, in_stride, in_origin, in_len, ch_first, n_channels, k0, kc, (float *)e->d_obuf.p,
+                                     (size_t)kc * H, k0 * (int64_t)H, s, timed && k0 == hop_first);
+            e->as_pitch1 = false;
+            if (rcr) return rcr;
+            rc::ResampleParams r{};
+            r.obuf = (const float *)e->d_obuf.p;
+            r.o_stride = (size_t)kc * H;
+            r.out = d_out;
+            r.out_stride = out_stride;
+            r.out_origin = out_origin;
+            r.hop_first = k0;
+            r.hop_count = kc;
+            r.n_channels = n_channels;
+            r.half = H;
+            r.samples_needed = (uint32_t)e->par.samples_needed_per_window;
+            r.window_out_len = e->par.window_out_len;
+            r.f = (uint32_t)(-e->cfg.pitch_multiple);
+            RC_HIP(rc::launch_resample_slower(r, s));
+        }
+        return RC_OK;
+    }
     if (band_fused) {
         const uint32_t half = e->par.window_len / 2;
         const uint32_t lo = e->cfg.dk_lo_bin, hi = std::min<uint32_t>(e->cfg.dk_hi_bin, half);
@@ -735,7 +771,7 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
 #ifndef RC_BIG4
 #define RC_BIG4 1
 #endif
-    if (RC_BIG4 && e->log2n > 14 && !e->cfg.kernel && !devk && e->cfg.pitch_multiple >= 1 &&
+    if (RC_BIG4 && e->log2n > 14 && !e->cfg.kernel && !devk && pos_pitch &&
         !(e->diag_flags & rc::RC_DIAG_PREV_KERNEL)) {
         // fused large-window kernel: one workgroup (512 threads, ~150 KB of LDS: one per CU) per run of hops;
         // each run recomputes the hop before it for its tail
@@ -1287,6 +1323,7 @@ void rc_engine_destroy(rc_engine *e) {
     e->d_spec2.release();
     e->d_ybuf.release();
     e->d_ysub.release();
+    e->d_obuf.release();
     e->d_tail.release();
     e->d_hop_in.release();
     e->d_hop_out.release();

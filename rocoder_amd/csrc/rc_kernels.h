@@ -182,6 +182,20 @@ hipError_t launch_hopw11(const HopParams &p, hipStream_t s);
 hipError_t launch_hopw2(const HopParams &p, hipStream_t s);
 // tail_only: just save y_{last}[H..] of the chunk as the carried tail (no output written)
 hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only = false);
+// resample_slower (src/resampler.rs:20-35) after a FUSED launch at pitch 1: hop k of channel c has its H overlap-added
+// samples at obuf + c * o_stride + (k - hop_first) * H; its window is the (S - 1) f samples lerp(O[i], O[i + 1], j / f)
+// at out + c * out_stride + (k * window_out_len - out_origin) (one hop per window; the rest of the half window is
+// dropped as in the reference, src/stretcher.rs:108-111)
+struct ResampleParams {
+    const float *obuf;
+    size_t o_stride;
+    float *out;
+    size_t out_stride;
+    int64_t out_origin;
+    int64_t hop_first, hop_count;
+    uint32_t n_channels, half, samples_needed, window_out_len, f;
+};
+hipError_t launch_resample_slower(const ResampleParams &p, hipStream_t s);
 // stage 0 = A (forward quarter FFTs), 1 = B (radix-4 + middle + radix-4), 2 = C (inverse quarter FFTs)
 // mode selects stage B's variant (user-kernel path: MODE_FORWARD, host apply(), MODE_RESYNTH)
 hipError_t launch_big(int stage, const BigParams &p, hipStream_t s, HopMode mode = MODE_FUSED);

@@ -434,6 +434,31 @@ hipError_t launch_prep(const PrepParams &p, hipStream_t s) {
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void resample_slower_kernel(const ResampleParams p) {
+    const int64_t hl = blockIdx.x;
+    const uint32_t ch = blockIdx.y, f = p.f;
+    GF o = (GF)p.obuf + (size_t)ch * p.o_stride + (size_t)hl * p.half;
+    GFW dst = (GFW)p.out + (size_t)ch * p.out_stride + ((p.hop_first + hl) * (int64_t)p.window_out_len - p.out_origin);
+    for (uint32_t m = threadIdx.x; m < p.window_out_len; m += blockDim.x) {
+        const uint32_t i = m / f, j = m - i * f;
+        const float cur = o[i], nxt = o[i + 1];
+        dst[m] = cur + (nxt - cur) * ((float)j / (float)f);  // math::lerp, src/math.rs:28-30
+    }
+}
+hipError_t launch_resample_slower(const ResampleParams &p, hipStream_t s) {
+    const int64_t per = 1 << 20;
+    for (int64_t h0 = 0; h0 < p.hop_count; h0 += per) {
+        ResampleParams q = p;
+        q.obuf = p.obuf + (size_t)h0 * p.half;
+        q.hop_first = p.hop_first + h0;
+        q.hop_count = std::min<int64_t>(per, p.hop_count - h0);
+        hipLaunchKernelGGL(resample_slower_kernel, dim3((unsigned)q.hop_count, p.n_channels), dim3(256), 0, s, q);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only) {
     const dim3 grid((unsigned)p.hop_count, p.n_channels), block(256);
     if (!tail_only) {

@@ -159,10 +159,14 @@ def test_large_window_streaming_equals_offline():
 
 @pytest.mark.parametrize("N,L,f,p,ch", [(256, 3000, 1.5, -2, 1), (1024, 20000, 4.0, -3, 2),
                                         (16384, 120000, 8.0, -2, 2), (4096, 30000, 4.0, -5, 1),
-                                        (32768, 150000, 6.0, -2, 1)])
+                                        (32768, 150000, 6.0, -2, 1), (65536, 500000, 16.0, -3, 2), (512, 20000, 8.0, -2, 2),
+                                        (2048, 60000, 2.0, -4, 1), (8192, 200000, 8.0, -2, 3), (16384, 700000, 1.0, -7, 1),
+                                        (3000, 40000, 3.0, -2, 1)])
 def test_negative_pitch_multiples_match_oracle(N, L, f, p, ch):
     """Subharmonic shifts: resample_slower (src/resampler.rs:20-35), (S-1)*|p| samples per window
-    (src/stretcher.rs:47-51,108-113), including the reference's sample dropping for |p| >= 3."""
+    (src/stretcher.rs:47-51,108-113), including the reference's sample dropping for |p| >= 3. The fused kernels compute
+    the pitch-1 overlap-add into scratch and resample_slower_kernel interpolates each window out of it (window lengths
+    that are not a power of two: the chirp-z path and the gather-form overlap-add)."""
     ra = _engine_mod()
     x = np.stack([onp.synth_input(c, L) for c in range(ch)])
     got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=0x5EED)
