@@ -11,9 +11,9 @@ hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<
 inp, outp = f"{d}/rc_in.wav", f"{d}/rc_out.wav"
 open(inp, "wb").write(hdr + data)
 exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "rocoder_amd", "bin", "rocoder")
-for i in range(2):
+for i, extra in enumerate(([], [], ["--devices", "0"], ["--devices", "0"])):
     t0 = time.perf_counter()
-    r = subprocess.run([exe, "-i", inp, "-o", outp, "-w", "16384", "-f", "8"], capture_output=True, text=True, env=dict(os.environ, ROCODER_CLI_TIMING="1"))
+    r = subprocess.run([exe, "-i", inp, "-o", outp, "-w", "16384", "-f", "8", *extra], capture_output=True, text=True, env=dict(os.environ, ROCODER_CLI_TIMING="1"))
     dt = time.perf_counter() - t0
-    print(f"run {i}: rc={r.returncode} {dt:.2f} s, out {os.path.getsize(outp)/1e9:.2f} GB", r.stderr[-500:].replace("\n", " | "))
+    print(f"run {i} {extra}: rc={r.returncode} {dt:.2f} s, out {os.path.getsize(outp)/1e9:.2f} GB", r.stderr[-500:].replace("\n", " | "))
 os.remove(inp); os.remove(outp)
