@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 3 /* 3: + rc_shard_plan / rc_multi_* (struct layouts unchanged since 2) */
+#define RC_ABI_VERSION 4 /* 3: + rc_shard_plan / rc_multi_*; 4: + rc_engine_next_window_view, rc_multi_set_staging,
+                          * rc_calib_valu (struct layouts unchanged since 2) */
 
 /* status codes */
 #define RC_OK 0
@@ -140,6 +141,12 @@ int rc_engine_close_input(rc_engine *e, uint32_t channel);
  * RC_WOULD_BLOCK when the reference would block waiting for input. */
 int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out_cap,
                           size_t *n_out);
+/* The same hand-out without the copy: *window points at the window's window_out_len samples inside the engine's
+ * pinned host block, valid until the next rc_engine_next_window / _view call on the SAME channel. The reference moves
+ * a freshly allocated Vec<f32> into the bounded queue (src/stretcher.rs:112-120, src/stretcher_processor.rs:69); a
+ * host that writes the window straight to its sink (src/main.rs:197-203: the WAV writer) needs no Vec at all. On a
+ * closed channel (whole input known) the batch after the one being handed out is computed and copied meanwhile. */
+int rc_engine_next_window_view(rc_engine *e, uint32_t channel, const float **window, size_t *n_out);
 /* Stretcher::is_done (src/stretcher.rs:78-80): 1 / 0, or <0 on error. */
 int rc_engine_is_done(const rc_engine *e, uint32_t channel);
 /* Stretcher::channel_bound (src/stretcher.rs:82-85) */
@@ -213,6 +220,10 @@ typedef struct rc_multi rc_multi;
 int rc_multi_create(const rc_config *cfg, const int32_t *device_ids, uint32_t n_devices, rc_multi **out);
 void rc_multi_destroy(rc_multi *m);
 uint32_t rc_multi_device_count(const rc_multi *m);
+/* Diagnostic: in the device form a share that runs on the root's own device (the root itself, or the root device
+ * listed again) reads and writes the caller's tensors in place. force != 0 makes such shares take the span-copy /
+ * shard-copy path of a remote device as well, so that a one-GPU box exercises it. Default 0. */
+int rc_multi_set_staging(rc_multi *m, int force);
 /* rc_engine_stretch_host over all listed devices: each uploads the span of input its shards read and downloads
  * its shards into out[c]. Blocking. */
 int rc_multi_stretch_host(rc_multi *m, const float *const *in, size_t in_len, float *const *out, size_t out_cap,
@@ -223,6 +234,13 @@ int rc_multi_stretch_host(rc_multi *m, const float *const *in, size_t in_len, fl
  * synchronised on entry. Blocking: d_out is complete on return. */
 int rc_multi_stretch_device(rc_multi *m, uint32_t root, const float *d_in, size_t in_stride, size_t in_len,
                             float *d_out, size_t out_stride, size_t out_cap, size_t *out_len, void *hip_stream);
+
+/* ---- measurement support -------------------------------------------------------------------
+ * Box calibration for bench.py (boxes of one pool differ by several per cent on the same binary): runs a fixed
+ * pure-VALU kernel (independent v_pk_fma_f32 chains, eight waves per SIMD, no memory traffic) `launches` times on
+ * `hip_stream` of `device` and returns the mean duration of one launch in *ms_per_launch and the time one packed-FMA
+ * wave instruction takes on one SIMD in *ns_per_inst. Not on the reference's path. */
+int rc_calib_valu(int device, void *hip_stream, uint32_t launches, float *ms_per_launch, float *ns_per_inst);
 
 #ifdef __cplusplus
 }

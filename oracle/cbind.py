@@ -43,26 +43,27 @@ _base = None
 
 
 def cpu_baseline_stretch(channels_in, window_len=16384, factor=1.0, amplitude=1.0, pitch_multiple=1,
-                         seed=0, threads=1) -> np.ndarray:
+                         seed=0, threads=1, ch_first=0) -> np.ndarray:
     """oracle/rocoder_cpu_baseline.c: the reference's algorithm written for speed (optimised FFT,
-    optional OpenMP over hop ranges) - what bench.py times as `cpu_baseline`. [C, L] -> [C, n_out]."""
+    optional OpenMP over hop ranges) - what bench.py times as `cpu_baseline`. [C, L] -> [C, n_out].
+    `ch_first`: the rows are channels ch_first.. of a larger job (the phase key takes the job's channel index)."""
     global _base
     if _base is None:
         build()
         _base = C.CDLL(_SO_BASE)
         _base.rcb_output_len.restype = C.c_size_t
         _base.rcb_output_len.argtypes = [C.c_size_t, C.c_uint32, C.c_float, C.c_int]
-        _base.rcb_stretch.restype = C.c_int
-        _base.rcb_stretch.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_uint32, C.c_uint32, C.c_float,
-                                      C.c_float, C.c_int, C.c_uint64, C.POINTER(C.c_float), C.c_int]
+        _base.rcb_stretch_from.restype = C.c_int
+        _base.rcb_stretch_from.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.c_float, C.c_float, C.c_int, C.c_uint64, C.POINTER(C.c_float), C.c_int]
     x = np.ascontiguousarray(np.atleast_2d(channels_in), dtype=np.float32)
     nch, length = x.shape
     n_out = _base.rcb_output_len(length, window_len, factor, pitch_multiple)
     if n_out == 0:
         raise ValueError("unsupported parameters for the CPU baseline")
     out = np.zeros((nch, n_out), np.float32)
-    rc = _base.rcb_stretch(_fp(x), length, nch, window_len, factor, amplitude, pitch_multiple, seed,
-                           _fp(out), threads)
+    rc = _base.rcb_stretch_from(_fp(x), length, nch, ch_first, window_len, factor, amplitude, pitch_multiple,
+                                seed, _fp(out), threads)
     if rc != 0:
         raise ValueError(f"rcb_stretch rc={rc}")
     return out

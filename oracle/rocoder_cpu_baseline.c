@@ -207,8 +207,16 @@ size_t rcb_output_len(size_t L, uint32_t N, float factor, int pitch) {
 
 /* in: [C][L] (stride L), out: [C][rcb_output_len] ; threads <= 1: one DSP thread for all channels.
  * Returns 0, or -1 for unsupported parameters. */
+int rcb_stretch_from(const float *in, size_t L, uint32_t C, uint32_t ch_first, uint32_t N, float factor,
+                     float amplitude, int pitch, uint64_t seed, float *out, int threads);
 int rcb_stretch(const float *in, size_t L, uint32_t C, uint32_t N, float factor, float amplitude, int pitch,
                 uint64_t seed, float *out, int threads) {
+    return rcb_stretch_from(in, L, C, 0, N, factor, amplitude, pitch, seed, out, threads);
+}
+/* The same for rows that are channels ch_first .. ch_first + C - 1 of a larger job (the phase key takes the
+ * job's channel index): lets a test check one channel of a BASELINE-size job at a time. */
+int rcb_stretch_from(const float *in, size_t L, uint32_t C, uint32_t ch_first, uint32_t N, float factor,
+                     float amplitude, int pitch, uint64_t seed, float *out, int threads) {
     const size_t n_out = rcb_output_len(L, N, factor, pitch);
     if (!n_out) return -1;
     const uint32_t H = N / 2;
@@ -259,7 +267,7 @@ int rcb_stretch(const float *in, size_t L, uint32_t C, uint32_t N, float factor,
             const int64_t k0 = (sgi % seg_per_ch) * seg_len;
             int64_t k1 = k0 + seg_len;
             if (k1 > K) k1 = K;
-            if (k0 < k1) hop_range(&j, &pl, in + (size_t)c * L, L, c, k0, k1, out + (size_t)c * n_out, buf, y, tail);
+            if (k0 < k1) hop_range(&j, &pl, in + (size_t)c * L, L, ch_first + c, k0, k1, out + (size_t)c * n_out, buf, y, tail);
         }
         free(pl.work);
         free(buf);

@@ -95,6 +95,7 @@ SYMBOLS = {
     "rc_engine_push_input": (C.c_int, [_eng, C.c_uint32, _fp, _sz]),
     "rc_engine_close_input": (C.c_int, [_eng, C.c_uint32]),
     "rc_engine_next_window": (C.c_int, [_eng, C.c_uint32, _fp, _sz, C.POINTER(_sz)]),
+    "rc_engine_next_window_view": (C.c_int, [_eng, C.c_uint32, C.POINTER(_fp), C.POINTER(_sz)]),
     "rc_engine_is_done": (C.c_int, [_eng, C.c_uint32]),
     "rc_engine_channel_bound": (_sz, [_eng]),
     "rc_engine_stretch_host": (C.c_int, [_eng, C.POINTER(_fp), _sz, C.POINTER(_fp), _sz,
@@ -114,9 +115,11 @@ SYMBOLS = {
     "rc_multi_create": (C.c_int, [C.POINTER(rc_config), C.POINTER(C.c_int32), C.c_uint32, C.POINTER(_eng)]),
     "rc_multi_destroy": (None, [_eng]),
     "rc_multi_device_count": (C.c_uint32, [_eng]),
+    "rc_multi_set_staging": (C.c_int, [_eng, C.c_int]),
     "rc_multi_stretch_host": (C.c_int, [_eng, C.POINTER(_fp), _sz, C.POINTER(_fp), _sz, C.POINTER(_sz)]),
     "rc_multi_stretch_device": (C.c_int, [_eng, C.c_uint32, C.c_void_p, _sz, _sz, C.c_void_p, _sz, _sz,
                                           C.POINTER(_sz), C.c_void_p]),
+    "rc_calib_valu": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, _fp, _fp]),
 }
 
 _lib = None

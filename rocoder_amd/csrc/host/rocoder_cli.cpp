@@ -365,15 +365,23 @@ struct KernelStack {
         auto *self = (KernelStack *)user;
         for (;;) {
             rc_freq_kernel fn = nullptr;
+            void *handle = nullptr;
             {
                 std::lock_guard<std::mutex> lk(self->m);
                 if (self->libs.empty()) return 1;  // no-op
+                handle = self->libs.back().first;
                 fn = self->libs.back().second;
             }
             if (fn(t, in, out, n, nullptr) == 0) return 0;
             fprintf(stderr, "WARN kernel panicked, retrying with last or noop.\n");  // fft.rs:101
+            // pop the library that FAILED, not whatever is on top now: the watcher thread may have pushed a newer one
+            // between the call and this line (the reference cannot race here: same thread, fft.rs:78-106)
             std::lock_guard<std::mutex> lk(self->m);
-            if (!self->libs.empty()) self->libs.pop_back();
+            for (size_t i = self->libs.size(); i-- > 0;)
+                if (self->libs[i].first == handle) {
+                    self->libs.erase(self->libs.begin() + (long)i);
+                    break;
+                }
         }
     }
 };

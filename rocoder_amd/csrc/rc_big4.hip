@@ -157,6 +157,12 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
 #ifndef RC_B4_LB
 #define RC_B4_LB 16  // R = 64: input rows in flight per batch (8 pairs; 32 leave no room next to the register tail)
 #endif
+#ifndef RC_B4_PIPE
+#define RC_B4_PIPE 1  // R = 64, default window: input rows as a two-deep pipeline of RC_B4_PIPE_LB-row batches (-0.7 %; 8 rows: flat, 32 rows = all in flight: +1.5 %)
+#endif
+#ifndef RC_B4_PIPE_LB
+#define RC_B4_PIPE_LB 16
+#endif
 #ifndef RC_B4_TAILREG_MAX
 #define RC_B4_TAILREG_MAX 64  // largest R whose carried tail lives in registers (above: per-workgroup scratch)
 #endif
@@ -167,7 +173,8 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
 // addresses) may still be in flight when the next hop starts
 #define BIG4_BAR()                                                                       \
     do {                                                                                 \
-        if (RC_B4_LGKM) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
+        if (RC_B4_ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+        else if (RC_B4_LGKM) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
         else __syncthreads();                                                            \
     } while (0)
 #ifndef RC_B4_TAILNT
@@ -184,6 +191,12 @@ __device__ __forceinline__ void tail_st(GV2W p, v2f v) {
 #ifndef RC_B4_ABL
 #define RC_B4_ABL 0  // timing-only ablations of big4_kernel: 1 no input loads, 2 no tail scratch traffic, 4 no output stores
 #endif
+// (timing-only, RC_B4_ABL bit 8: the E2 / E3 barriers become compiler fences - what desynchronised waves would buy)
+#define BIG4_BAR_MID()                                                          \
+    do {                                                                        \
+        if (RC_B4_ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+        else BIG4_BAR();                                                        \
+    } while (0)
 #ifndef RC_B4_EB
 #define RC_B4_EB 4
 #endif
@@ -331,6 +344,49 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             // brev(q) and brev(q) + 1), and the compiler folds the second row's window multiply into that butterfly, so a
             // row loaded long before its partner would wait for it as two live values (raw samples and window)
 #define ROW(i) (RC_B4_PAIRLOAD ? (((i) >> 1) + ((i) & 1) * (R / 2)) : (i))
+            if constexpr (RC_B4_PIPE && HANN && R == 64 && RC_B4_PAIRLOAD && !DMA) {
+                // Two batches of rows in flight: batch i + 2 is requested as soon as batch i has been folded into
+                // v[] (stage 0), so a hop exposes about one memory latency instead of one per batch. The window
+                // values are computed pair by pair inside the fold (hoisted over a whole batch they are LB more
+                // live pairs, and the allocator spills)
+                constexpr int PB = RC_B4_PIPE_LB, NB = R / PB;
+                float xp0[2][PB], xp1[2][PB];
+                auto issue = [&](int i, float (&x0)[PB], float (&x1)[PB]) {
+#pragma unroll
+                    for (int q = 0; q < PB; ++q) {
+                        if (RC_B4_ABL & 1) {
+                            x0[q] = (float)(lane2 + ROW(i * PB + q)) + (float)k;
+                            x1[q] = x0[q] * 0.5f;
+                        } else {
+                            x0[q] = (src + 2 * T * ROW(i * PB + q))[lane2];
+                            x1[q] = (src + 2 * T * ROW(i * PB + q))[lane2 + 1];
+                        }
+                    }
+                };
+                issue(0, xp0[0], xp1[0]);
+                issue(1, xp0[1], xp1[1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) {
+#pragma unroll
+                    for (int q = 0; q < PB; q += 2) {
+                        const int r0 = ROW(i * PB + q), r1 = ROW(i * PB + q + 1);
+                        const v2f w0 = __builtin_elementwise_fma(v2f{HW.s[r0], HW.s[r0]}, sbW,
+                                       __builtin_elementwise_fma(v2f{HW.c[r0], HW.c[r0]}, cbW, v2f{0.5f, 0.5f}));
+                        const v2f w1 = __builtin_elementwise_fma(v2f{HW.s[r1], HW.s[r1]}, sbW,
+                                       __builtin_elementwise_fma(v2f{HW.c[r1], HW.c[r1]}, cbW, v2f{0.5f, 0.5f}));
+                        const v2f a = v2f{xp0[i & 1][q], xp1[i & 1][q]} * w0;
+                        const v2f xh = v2f{xp0[i & 1][q + 1], xp1[i & 1][q + 1]};
+                        v[brev_c(r0, b)] = __builtin_elementwise_fma(xh, w1, a);
+                        v[brev_c(r0, b) + 1] = __builtin_elementwise_fma(-xh, w1, a);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i + 2 < NB) {
+                        issue(i + 2, xp0[i & 1], xp1[i & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            } else
 #pragma unroll
             for (int q0 = 0; q0 < R; q0 += LB) {
                 float xr0[LB], xr1[LB], wr0[HANN ? 1 : LB], wr1[HANN ? 1 : LB];
@@ -473,7 +529,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             const int b2s = lf | (uu << 10);
 #pragma unroll
             for (int rnd = 0; rnd < G; ++rnd) {
-                BIG4_BAR();
+                BIG4_BAR_MID();
                 if (OVL2 && rnd == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kk = 0; kk < 32; ++kk) {
@@ -493,7 +549,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                BIG4_BAR();
+                BIG4_BAR_MID();
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     if (R == 64 && ((s & 1) != rnd)) continue;
@@ -599,7 +655,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             const int tid = ptid(), l4 = tid & 15, hi = tid >> 4;
 #pragma unroll
             for (int rnd = 0; rnd < G; ++rnd) {
-                BIG4_BAR();
+                BIG4_BAR_MID();
                 if (OVL3 && rnd == 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
@@ -625,7 +681,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                BIG4_BAR();
+                BIG4_BAR_MID();
 #pragma unroll
                 for (int kk = 0; kk < 32; ++kk) {
                     // R = 32: register kk = P4..P8; R = 64: kk = (group g = P14) << 4 | (P5..P8), P4 = rnd

@@ -22,6 +22,8 @@
 #include <system_error>
 #include <thread>
 #include <complex>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -180,11 +182,16 @@ struct Channel {
     uint64_t next_window = 0;  // next window index to COMPUTE
     uint64_t windows_out = 0;  // windows handed to the caller
     int64_t done_window = -1;  // window index whose hand-out sets is_done
-    // computed windows not handed out yet: one pinned block per channel (the D2H lands here at link speed and
-    // next_window copies one window out of it), windows [ready_pos, ready_n) are pending
-    float *ready_p = nullptr;
-    size_t ready_cap = 0;      // floats
+    // computed windows not handed out yet: two pinned blocks per channel. The D2H of a batch lands in one at link
+    // speed and next_window hands its windows out (a copy, or a pointer: rc_engine_next_window_view); on a closed
+    // channel the NEXT batch is already being computed and copied into the other block meanwhile (look-ahead).
+    // Windows [ready_pos, ready_n) of block `cur` are pending; `ahead_n` windows are in flight into block cur ^ 1.
+    float *blk_p[2] = {nullptr, nullptr};
+    size_t blk_cap[2] = {0, 0};  // floats
+    hipEvent_t blk_ev[2] = {nullptr, nullptr};
+    int cur = 0;
     uint64_t ready_pos = 0, ready_n = 0;
+    uint64_t ahead_n = 0;
 };
 
 }  // namespace
@@ -394,7 +401,7 @@ int check_device_error(rc_engine *e) {
 // chunk i - 2.
 int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uint32_t n_channels,
                     int64_t hop_first, int64_t hop_count, float *d_out, size_t out_stride,
-                    int64_t out_origin, hipStream_t s, uint32_t *launches) {
+                    int64_t out_origin, hipStream_t s, uint32_t *launches, bool *started) {
     rc_engine::KernelPipe &kp = e->kp;
     const uint32_t N = e->par.window_len, H = N / 2;
     const bool big = e->log2n > 14;
@@ -552,6 +559,7 @@ int run_hops_kernel(rc_engine *e, const rc::HopParams &p, uint32_t ch_first, uin
     };
     int i = 0;
     int64_t prev_k0 = 0, prev_kc = 0;
+    *started = true;  // from here on chunks advance d_tail and consume apply() calls: a failure cannot be retried in place
     for (int64_t k0 = hop_first; k0 < hop_first + hop_count; k0 += kc_max, ++i) {
         const int64_t kc = std::min<int64_t>(kc_max, hop_first + hop_count - k0);
         if (int rc = front(i, k0, kc)) return rc;
@@ -687,10 +695,16 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
         for (int64_t k0 = hop_first; k0 < hop_first + hop_count; k0 += piece) {
             const int64_t kc = std::min<int64_t>(piece, hop_first + hop_count - k0);
             if (int rcb = e->d_obuf.reserve((size_t)n_channels * kc * H * sizeof(float))) return rcb;
-            e->as_pitch1 = true;
-            const int rcr = run_hops(e, d_in, in_stride, in_origin, in_len, ch_first, n_channels, k0, kc, (float *)e->d_obuf.p,
-                                     (size_t)kc * H, k0 * (int64_t)H, s, timed && k0 == hop_first);
-            e->as_pitch1 = false;
+            int rcr;
+            {
+                struct AsPitch1 {  // cleared on every way out of the inner pass, exceptions included
+                    rc_engine *e;
+                    explicit AsPitch1(rc_engine *e_) : e(e_) { e->as_pitch1 = true; }
+                    ~AsPitch1() { e->as_pitch1 = false; }
+                } guard(e);
+                rcr = run_hops(e, d_in, in_stride, in_origin, in_len, ch_first, n_channels, k0, kc, (float *)e->d_obuf.p,
+                               (size_t)kc * H, k0 * (int64_t)H, s, timed && k0 == hop_first);
+            }
             if (rcr) return rcr;
             rc::ResampleParams r{};
             r.obuf = (const float *)e->d_obuf.p;
@@ -978,9 +992,16 @@ int run_hops(rc_engine *e, const float *d_in, size_t in_stride, int64_t in_origi
     else if (!e->cfg.kernel && (rc = run_chunk(hop_first - 1, 1, true)))
         return rc;
     if (e->cfg.kernel) {
+        bool started = false;
         if ((rc = run_hops_kernel(e, p, ch_first, n_channels, hop_first, hop_count, d_out, out_stride,
-                                  out_origin, s, &launches)))
-            return rc;  // (kernel_next_hop untouched: the caller may retry the same range)
+                                  out_origin, s, &launches, &started))) {
+            // Failed before any chunk ran (reserve / pinned allocation): nothing moved, the same range may be retried.
+            // Failed later: completed chunks have advanced d_tail and consumed stateful apply() calls, so a retry at
+            // hop_first would overlap-add the wrong tail - only a restart at hop 0 is accepted from here.
+            if (started)
+                for (uint32_t c = ch_first; c < ch_first + n_channels; ++c) e->kernel_next_hop[c] = -1;
+            return rc;
+        }
         for (uint32_t c = ch_first; c < ch_first + n_channels; ++c) e->kernel_next_hop[c] = hop_first + hop_count;
     } else
     for (int64_t k0 = hop_first; k0 < hop_first + hop_count; k0 += chunk_max) {
@@ -1350,7 +1371,10 @@ void rc_engine_destroy(rc_engine *e) {
         if (e->ev1[i]) (void)hipEventDestroy(e->ev1[i]);
     }
     for (auto &c : e->ch)
-        if (c.ready_p) (void)hipHostFree(c.ready_p);
+        for (int b = 0; b < 2; ++b) {
+            if (c.blk_p[b]) (void)hipHostFree(c.blk_p[b]);
+            if (c.blk_ev[b]) (void)hipEventDestroy(c.blk_ev[b]);
+        }
     for (int i = 0; i < rc_engine::HostPipe::kWorkers; ++i) {
         if (e->hp.slot[i]) (void)hipHostFree(e->hp.slot[i]);
         if (e->hp.st[i]) (void)hipStreamDestroy(e->hp.st[i]);
@@ -1398,93 +1422,152 @@ int rc_engine_is_done(const rc_engine *e, uint32_t channel) {
     return (c.done_window >= 0 && (int64_t)c.windows_out > c.done_window) ? 1 : 0;
 }
 
-int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out_cap, size_t *n_out) try {
-    if (!e || channel >= e->ch.size() || !out) return fail(RC_EINVAL, "bad argument");
+namespace {
+// How many whole windows of the channel can be computed now: RC_OK with *nwin > 0, or RC_WOULD_BLOCK (more input
+// needed), or RC_EINVAL (called after is_done).
+//  hop h needs samples [h*step, h*step+N); on a closed channel the shortfall is zero padded and `done` is raised at
+//  the first short hop (src/stretcher.rs:123-135).
+int stream_plan(rc_engine *e, Channel &c, uint64_t *nwin_out) {
+    const rc_params &P = e->par;
+    const uint32_t N = P.window_len, hpw = P.hops_per_window, step = P.sample_step_len, wout = P.window_out_len;
+    const uint64_t k0 = c.next_window * hpw;
+    uint64_t nwin = 0;
+    if (c.closed) {
+        if (c.done_window >= 0 && (int64_t)c.next_window > c.done_window)
+            return fail(RC_EINVAL, "next_window called after is_done (src/stretcher_processor.rs:64-68 never does)");
+        const uint64_t kd = c.total_in >= N ? (c.total_in - N) / step + 1 : 0;
+        const uint64_t last_win = kd / hpw;  // window containing the first short hop
+        nwin = last_win + 1 - c.next_window;
+        c.done_window = (int64_t)last_win;
+    } else {
+        if (c.total_in < N) return RC_WOULD_BLOCK;
+        const uint64_t full_hops = (c.total_in - N) / step + 1;  // hops 0..full_hops-1 are complete
+        if (full_hops < k0 + hpw) return RC_WOULD_BLOCK;
+        nwin = (full_hops - k0) / hpw;
+    }
+    uint64_t max_hops = e->cfg.max_batch_hops ? e->cfg.max_batch_hops : 2048;
+    // live mode: never run further ahead than the bounded output queue would
+    // (src/stretcher_processor.rs:34, src/stretcher.rs:82-85) unless the whole input is known
+    uint64_t max_win = std::max<uint64_t>(1, max_hops / hpw);
+    if (!c.closed) max_win = std::min<uint64_t>(max_win, std::max<size_t>(1, rc_engine_channel_bound(e)));
+    // a host frequency kernel may be stateful: no look-ahead, so that the processor's round-robin over the
+    // channels (src/stretcher_processor.rs:63-70: windows outer, channels inner) is also the order in
+    // which apply() sees the hops
+    if (e->cfg.kernel) max_win = 1;
+    // one batch fills at most 16 MiB of a pinned block
+    max_win = std::min<uint64_t>(max_win, std::max<uint64_t>(1, (((size_t)16 << 20) / sizeof(float)) / wout));
+    *nwin_out = std::min<uint64_t>(nwin, max_win);
+    return RC_OK;
+}
+// Enqueues (no wait) the next `nwin` windows of the channel on the engine's stream: input span up, the hops, the
+// batch down into pinned block `blk`, an event behind it. Advances c.next_window and trims the input history.
+int stream_enqueue(rc_engine *e, uint32_t channel, uint64_t nwin, int blk) {
+    Channel &c = e->ch[channel];
+    const rc_params &P = e->par;
+    const uint32_t N = P.window_len, hpw = P.hops_per_window, step = P.sample_step_len, wout = P.window_out_len;
+    const uint64_t k0 = c.next_window * hpw, hop_count = nwin * hpw;
+    // input span: from the hop before k0 (its tail is recomputed) unless a user kernel
+    // carries the tail on the device
+    const bool recompute = !e->cfg.kernel && k0 > 0;
+    const uint64_t span_lo = (recompute ? k0 - 1 : k0) * (uint64_t)step;
+    const uint64_t span_hi = std::min<uint64_t>(c.total_in, (k0 + hop_count - 1) * (uint64_t)step + N);
+    if (span_lo < c.fifo_base) return fail(RC_EINVAL, "internal: input history dropped");
+    const size_t span = span_hi > span_lo ? (size_t)(span_hi - span_lo) : 0;
+    int rc;
+    RC_HIP(hipSetDevice(e->device));
+    // (the scratch is shared by the channels' batches: they follow one another on the engine's stream, and a
+    // reserve() that has to grow it frees the old block, which waits for the device)
+    if ((rc = e->d_in.reserve(std::max<size_t>(span, 1) * sizeof(float)))) return rc;
+    if ((rc = e->d_out.reserve((size_t)nwin * wout * sizeof(float)))) return rc;
+    if (c.blk_cap[blk] < (size_t)nwin * wout) {
+        if (c.blk_p[blk]) RC_HIP(hipHostFree(c.blk_p[blk]));
+        c.blk_p[blk] = nullptr;
+        c.blk_cap[blk] = 0;
+        RC_HIP(hipHostMalloc((void **)&c.blk_p[blk], (size_t)nwin * wout * sizeof(float), hipHostMallocDefault));
+        c.blk_cap[blk] = (size_t)nwin * wout;
+    }
+    if (!c.blk_ev[blk]) RC_HIP(hipEventCreateWithFlags(&c.blk_ev[blk], hipEventDisableTiming));
+    if (span)  // (pageable source: the runtime has consumed it when the call returns)
+        RC_HIP(hipMemcpyAsync(e->d_in.p, c.fifo.data() + (span_lo - c.fifo_base), span * sizeof(float),
+                              hipMemcpyHostToDevice, e->stream));
+    rc = run_hops(e, (const float *)e->d_in.p, 0, (int64_t)span_lo, (int64_t)span, channel, 1,
+                  (int64_t)k0, (int64_t)hop_count, (float *)e->d_out.p, 0,
+                  (int64_t)(c.next_window * wout), e->stream, false);
+    if (rc) return rc;
+    RC_HIP(hipMemcpyAsync(c.blk_p[blk], e->d_out.p, (size_t)nwin * wout * sizeof(float), hipMemcpyDeviceToHost,
+                          e->stream));
+    RC_HIP(hipEventRecord(c.blk_ev[blk], e->stream));
+    c.next_window += nwin;
+    // drop input no later hop needs (keep from (next hop - 1) * step) once it is at least half of what is
+    // held: erasing the front of the vector every batch would move the whole remainder each time
+    const uint64_t keep_from = (c.next_window * hpw > 0 ? c.next_window * hpw - 1 : 0) * (uint64_t)step;
+    if (keep_from > c.fifo_base) {
+        const uint64_t drop = std::min<uint64_t>(keep_from - c.fifo_base, c.fifo.size());
+        if (drop * 2 >= c.fifo.size()) {
+            c.fifo.erase(c.fifo.begin(), c.fifo.begin() + drop);
+            c.fifo_base += drop;
+        }
+    }
+    return RC_OK;
+}
+// The window the next hand-out of the channel delivers, computing / waiting as needed: *win points into the
+// channel's pinned block (valid until the next hand-out of the same channel).
+int stream_next(rc_engine *e, uint32_t channel, const float **win) {
     int rc = check_device_error(e);
     if (rc) return rc;
     Channel &c = e->ch[channel];
-    const rc_params &P = e->par;
-    const uint32_t N = P.window_len, hpw = P.hops_per_window, step = P.sample_step_len;
-    const uint32_t wout = P.window_out_len;
-    if (out_cap < wout) return fail(RC_ECAPACITY, "out_cap %zu < window_out_len %u", out_cap, wout);
+    const uint32_t wout = e->par.window_out_len;
     if (c.ready_pos == c.ready_n) {
-        // how many whole windows can be computed now?
-        //  hop h needs samples [h*step, h*step+N); on a closed channel the shortfall is zero
-        //  padded and `done` is raised at the first short hop (src/stretcher.rs:123-135).
-        const uint64_t k0 = c.next_window * hpw;
-        uint64_t nwin = 0;
-        if (c.closed) {
-            if (c.done_window >= 0 && (int64_t)c.next_window > c.done_window)
-                return fail(RC_EINVAL, "next_window called after is_done (src/stretcher_processor.rs:64-68 never does)");
-            const uint64_t kd = c.total_in >= N ? (c.total_in - N) / step + 1 : 0;
-            const uint64_t last_win = kd / hpw;  // window containing the first short hop
-            nwin = last_win + 1 - c.next_window;
-            c.done_window = (int64_t)last_win;
+        if (c.ahead_n) {  // the look-ahead batch: wait for its copy, make its block the current one
+            RC_HIP(hipEventSynchronize(c.blk_ev[c.cur ^ 1]));
+            c.cur ^= 1;
+            c.ready_n = c.ahead_n;
+            c.ahead_n = 0;
         } else {
-            if (c.total_in < N) return RC_WOULD_BLOCK;
-            const uint64_t full_hops = (c.total_in - N) / step + 1;  // hops 0..full_hops-1 are complete
-            if (full_hops < k0 + hpw) return RC_WOULD_BLOCK;
-            nwin = (full_hops - k0) / hpw;
+            uint64_t nwin = 0;
+            if ((rc = stream_plan(e, c, &nwin))) return rc;
+            if ((rc = stream_enqueue(e, channel, nwin, c.cur))) return rc;
+            RC_HIP(hipEventSynchronize(c.blk_ev[c.cur]));
+            c.ready_n = nwin;
         }
-        uint64_t max_hops = e->cfg.max_batch_hops ? e->cfg.max_batch_hops : 2048;
-        // live mode: never run further ahead than the bounded output queue would
-        // (src/stretcher_processor.rs:34, src/stretcher.rs:82-85) unless the whole input is known
-        uint64_t max_win = std::max<uint64_t>(1, max_hops / hpw);
-        if (!c.closed) max_win = std::min<uint64_t>(max_win, std::max<size_t>(1, rc_engine_channel_bound(e)));
-        // a host frequency kernel may be stateful: no look-ahead, so that the processor's round-robin over the
-        // channels (src/stretcher_processor.rs:63-70: windows outer, channels inner) is also the order in
-        // which apply() sees the hops
-        if (e->cfg.kernel) max_win = 1;
-        // one batch fills at most 16 MiB of the channel's pinned block
-        max_win = std::min<uint64_t>(max_win, std::max<uint64_t>(1, (((size_t)16 << 20) / sizeof(float)) / wout));
-        nwin = std::min<uint64_t>(nwin, max_win);
-        const uint64_t hop_count = nwin * hpw;
-        // input span: from the hop before k0 (its tail is recomputed) unless a user kernel
-        // carries the tail on the device
-        const bool recompute = !e->cfg.kernel && k0 > 0;
-        const uint64_t span_lo = (recompute ? k0 - 1 : k0) * (uint64_t)step;
-        const uint64_t span_hi = std::min<uint64_t>(c.total_in, (k0 + hop_count - 1) * (uint64_t)step + N);
-        if (span_lo < c.fifo_base) return fail(RC_EINVAL, "internal: input history dropped");
-        const size_t span = span_hi > span_lo ? (size_t)(span_hi - span_lo) : 0;
-        RC_HIP(hipSetDevice(e->device));
-        if ((rc = e->d_in.reserve(std::max<size_t>(span, 1) * sizeof(float)))) return rc;
-        if ((rc = e->d_out.reserve((size_t)nwin * wout * sizeof(float)))) return rc;
-        if (span)
-            RC_HIP(hipMemcpyAsync(e->d_in.p, c.fifo.data() + (span_lo - c.fifo_base), span * sizeof(float),
-                                  hipMemcpyHostToDevice, e->stream));
-        rc = run_hops(e, (const float *)e->d_in.p, 0, (int64_t)span_lo, (int64_t)span, channel, 1,
-                      (int64_t)k0, (int64_t)hop_count, (float *)e->d_out.p, 0,
-                      (int64_t)(c.next_window * wout), e->stream, false);
-        if (rc) return rc;
-        if (c.ready_cap < (size_t)nwin * wout) {
-            if (c.ready_p) RC_HIP(hipHostFree(c.ready_p));
-            c.ready_p = nullptr;
-            c.ready_cap = 0;
-            RC_HIP(hipHostMalloc((void **)&c.ready_p, (size_t)nwin * wout * sizeof(float), hipHostMallocDefault));
-            c.ready_cap = (size_t)nwin * wout;
-        }
-        RC_HIP(hipMemcpyAsync(c.ready_p, e->d_out.p, (size_t)nwin * wout * sizeof(float), hipMemcpyDeviceToHost,
-                              e->stream));
-        RC_HIP(hipStreamSynchronize(e->stream));
-        if ((rc = check_device_error(e))) return rc;
         c.ready_pos = 0;
-        c.ready_n = nwin;
-        c.next_window += nwin;
-        // drop input no later hop needs (keep from (next hop - 1) * step) once it is at least half of what is
-        // held: erasing the front of the vector every batch would move the whole remainder each time
-        const uint64_t keep_from = (c.next_window * hpw > 0 ? c.next_window * hpw - 1 : 0) * (uint64_t)step;
-        if (keep_from > c.fifo_base) {
-            const uint64_t drop = std::min<uint64_t>(keep_from - c.fifo_base, c.fifo.size());
-            if (drop * 2 >= c.fifo.size()) {
-                c.fifo.erase(c.fifo.begin(), c.fifo.begin() + drop);
-                c.fifo_base += drop;
+        if ((rc = check_device_error(e))) return rc;
+        // Look-ahead: with the whole input known (closed channel) and no host kernel (whose apply() order is the
+        // processor's), the following batch is enqueued now and overlaps the hand-out of this one. A live channel
+        // keeps to the bounded queue's look-ahead (stream_plan) and computes when asked.
+        if (c.closed && !e->cfg.kernel && !(c.done_window >= 0 && (int64_t)c.next_window > c.done_window)) {
+            uint64_t nwin = 0;
+            if (stream_plan(e, c, &nwin) == RC_OK && nwin) {
+                if ((rc = stream_enqueue(e, channel, nwin, c.cur ^ 1))) return rc;
+                c.ahead_n = nwin;
             }
         }
     }
-    memcpy(out, c.ready_p + (size_t)c.ready_pos * wout, (size_t)wout * sizeof(float));
-    if (n_out) *n_out = wout;
+    *win = c.blk_p[c.cur] + (size_t)c.ready_pos * wout;
     c.ready_pos++;
     c.windows_out++;
+    return RC_OK;
+}
+}  // namespace
+
+int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out_cap, size_t *n_out) try {
+    if (!e || channel >= e->ch.size() || !out) return fail(RC_EINVAL, "bad argument");
+    const uint32_t wout = e->par.window_out_len;
+    if (out_cap < wout) return fail(RC_ECAPACITY, "out_cap %zu < window_out_len %u", out_cap, wout);
+    const float *win = nullptr;
+    if (int rc = stream_next(e, channel, &win)) return rc;
+    memcpy(out, win, (size_t)wout * sizeof(float));
+    if (n_out) *n_out = wout;
+    return RC_OK;
+} catch (...) {
+    return rc_catch();
+}
+
+int rc_engine_next_window_view(rc_engine *e, uint32_t channel, const float **window, size_t *n_out) try {
+    if (!e || channel >= e->ch.size() || !window) return fail(RC_EINVAL, "bad argument");
+    *window = nullptr;
+    if (int rc = stream_next(e, channel, window)) return rc;
+    if (n_out) *n_out = e->par.window_out_len;
     return RC_OK;
 } catch (...) {
     return rc_catch();
@@ -1762,45 +1845,109 @@ size_t rc_shard_plan(uint32_t channels, uint64_t total_windows, uint32_t n_devic
     return n;
 }
 
-struct rc_multi {
-    rc_config cfg{};
-    rc_params par{};
-    std::vector<int> dev;
-    std::vector<rc_engine *> eng;
-    std::vector<hipStream_t> st;
-    std::vector<DevBuf> d_in, d_out;  // per listed device: its input span and its shards (non-root / host form)
-};
-
 namespace {
 struct WorkerResult {
     int rc = RC_OK;
     std::string msg;
 };
-// Runs fn(i) on one thread per listed device (the caller's thread takes device 0's share) and folds the results:
-// the first failure, with its thread's rc_last_error text re-posted on the calling thread.
-int for_each_device(rc_multi *m, const std::function<int(size_t)> &fn) {
-    const size_t n = m->eng.size();
-    std::vector<WorkerResult> res(n);
-    auto run = [&](size_t i) {
+// One persistent host thread per listed device beyond the first (the caller's thread takes index 0 and the share of
+// any thread that could not be started). A call posts ONE function for all indices, bumps the generation and waits
+// for the count of outstanding shares to reach zero: no thread is created or joined per call.
+struct MultiWorkers {
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    uint64_t gen = 0;
+    size_t pending = 0;
+    bool quit = false;
+    const std::function<int(size_t)> *fn = nullptr;
+    std::vector<WorkerResult> res;
+    std::vector<std::thread> th;  // th[i - 1] serves list index i (not joinable: that index has no thread)
+    void run_one(size_t i) {
         int rc;
         try {
-            rc = fn(i);
+            rc = (*fn)(i);
         } catch (...) {
             rc = rc_catch();
         }
         res[i].rc = rc;
-        if (rc != RC_OK) res[i].msg = g_err;
-    };
-    {
-        JoinedThreads th;
-        std::vector<size_t> mine{0};
-        for (size_t i = 1; i < n; ++i)
-            if (!th.start(run, i)) mine.push_back(i);
-        for (size_t i : mine) run(i);
-        th.join();
+        res[i].msg = rc != RC_OK ? g_err : std::string();
     }
-    for (size_t i = 0; i < n; ++i)
-        if (res[i].rc != RC_OK) return fail(res[i].rc, "device %d (list index %zu): %s", m->dev[i], i, res[i].msg.c_str());
+    void loop(size_t i) {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return quit || gen != seen; });
+                if (quit) return;
+                seen = gen;
+            }
+            run_one(i);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void start(size_t n) {
+        res.assign(n, WorkerResult{});
+        th.resize(n > 0 ? n - 1 : 0);
+        for (size_t i = 1; i < n; ++i) {
+            try {
+                th[i - 1] = std::thread([this, i] { loop(i); });
+            } catch (const std::system_error &) {  // the caller's thread runs that share
+            }
+        }
+    }
+    int run(const std::function<int(size_t)> &f) {
+        const size_t n = res.size();
+        size_t live = 0;
+        for (auto &t : th) live += t.joinable() ? 1 : 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            fn = &f;
+            pending = live;
+            ++gen;
+        }
+        cv_go.notify_all();
+        run_one(0);
+        for (size_t i = 1; i < n; ++i)
+            if (!th[i - 1].joinable()) run_one(i);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        fn = nullptr;
+        return RC_OK;
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cv_go.notify_all();
+        for (auto &t : th)
+            if (t.joinable()) t.join();
+        th.clear();
+    }
+};
+}  // namespace
+
+struct rc_multi {
+    rc_config cfg{};
+    rc_params par{};
+    std::vector<int> dev;
+    std::vector<rc_engine *> eng;
+    std::vector<DevBuf> d_in, d_out;  // per listed device: the input spans and the shards of ALL its pieces of a job
+    bool force_staging = false;       // rc_multi_set_staging
+    MultiWorkers workers;
+};
+
+namespace {
+// Runs fn(i) for every list index (persistent threads, MultiWorkers) and folds the results: the first failure, with
+// its thread's rc_last_error text re-posted on the calling thread.
+int for_each_device(rc_multi *m, const std::function<int(size_t)> &fn) {
+    m->workers.run(fn);
+    for (size_t i = 0; i < m->eng.size(); ++i)
+        if (m->workers.res[i].rc != RC_OK)
+            return fail(m->workers.res[i].rc, "device %d (list index %zu): %s", m->dev[i], i, m->workers.res[i].msg.c_str());
     return RC_OK;
 }
 // samples [lo, hi) of the input that the hops of windows [w0, w1) read, incl. the recomputed hop before them
@@ -1811,6 +1958,29 @@ void input_span(const rc_params &p, uint64_t w0, uint64_t w1, size_t in_len, siz
     *lo = (size_t)std::min<uint64_t>(a, in_len);
     *hi = (size_t)std::min<uint64_t>(b, in_len);
 }
+// the calling thread's current device is put back on every way out of an rc_multi_* call
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    }
+    ~DeviceRestore() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+// a device pointer handed to rc_multi_stretch_device must live on the root device of the list
+int check_on_device(const void *ptr, int dev, const char *what) {
+    if (!ptr) return RC_OK;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RC_EINVAL, "%s is not a device pointer", what);
+    }
+    if (at.type != hipMemoryTypeDevice || at.device != dev)
+        return fail(RC_EINVAL, "%s lives on device %d (memory type %d), not on the root device %d of the list", what,
+                    at.device, (int)at.type, dev);
+    return RC_OK;
+}
 }  // namespace
 
 int rc_multi_create(const rc_config *cfg, const int32_t *device_ids, uint32_t n_devices, rc_multi **out) try {
@@ -1819,6 +1989,7 @@ int rc_multi_create(const rc_config *cfg, const int32_t *device_ids, uint32_t n_
     if (cfg->kernel)
         return fail(RC_EUNSUPPORTED, "a host frequency kernel sees its channel's hops in order (src/fft.rs:76-108): "
                                      "not on a job cut over devices; use one engine or a device kernel");
+    DeviceRestore restore;
     std::unique_ptr<rc_multi, void (*)(rc_multi *)> m(new rc_multi, rc_multi_destroy);
     m->cfg = *cfg;
     if (int rc = rc_derive_params(cfg, &m->par)) return rc;
@@ -1829,9 +2000,6 @@ int rc_multi_create(const rc_config *cfg, const int32_t *device_ids, uint32_t n_
         if (int rc = rc_engine_create(&c, &e)) return rc;
         m->dev.push_back(device_ids[i]);
         m->eng.push_back(e);
-        m->st.push_back(nullptr);
-        RC_HIP(hipSetDevice(device_ids[i]));
-        RC_HIP(hipStreamCreateWithFlags(&m->st.back(), hipStreamNonBlocking));
     }
     m->d_in.resize(n_devices);
     m->d_out.resize(n_devices);
@@ -1845,6 +2013,7 @@ int rc_multi_create(const rc_config *cfg, const int32_t *device_ids, uint32_t n_
                     (void)hipGetLastError();
                 }
             }
+    m->workers.start(n_devices);
     *out = m.release();
     return RC_OK;
 } catch (...) {
@@ -1853,12 +2022,11 @@ int rc_multi_create(const rc_config *cfg, const int32_t *device_ids, uint32_t n_
 
 void rc_multi_destroy(rc_multi *m) {
     if (!m) return;
+    m->workers.stop();
+    DeviceRestore restore;
     for (size_t i = 0; i < m->eng.size(); ++i) {
         (void)hipSetDevice(m->dev[i]);
-        if (i < m->st.size() && m->st[i]) {
-            (void)hipStreamSynchronize(m->st[i]);
-            (void)hipStreamDestroy(m->st[i]);
-        }
+        (void)rc_engine_synchronize(m->eng[i]);
         if (i < m->d_in.size()) m->d_in[i].release();
         if (i < m->d_out.size()) m->d_out[i].release();
         rc_engine_destroy(m->eng[i]);
@@ -1868,22 +2036,53 @@ void rc_multi_destroy(rc_multi *m) {
 
 uint32_t rc_multi_device_count(const rc_multi *m) { return m ? (uint32_t)m->eng.size() : 0; }
 
+int rc_multi_set_staging(rc_multi *m, int force) {
+    if (!m) return fail(RC_EINVAL, "null argument");
+    m->force_staging = force != 0;
+    return RC_OK;
+}
+
 namespace {
 // one device's share of the job. src: where channel c's sample 0 lives (root device or host), with its stride;
-// dst likewise for the output. host = both are host memory.
+// dst likewise for the output. host = both are host memory. Every piece of the share has its own region of the
+// device's span / shard buffers, so nothing waits between pieces: copies in, compute and copies out are enqueued on
+// the engine's stream back to back and the thread synchronises once at the end.
 int multi_share(rc_multi *m, size_t i, const std::vector<rc_shard> &plan, bool host, int root_dev,
                 const float *src, size_t src_stride, const float *const *src_rows, size_t in_len, float *dst,
-                size_t dst_stride, float *const *dst_rows, bool is_root) {
+                size_t dst_stride, float *const *dst_rows) {
     const int dev = m->dev[i];
     rc_engine *e = m->eng[i];
-    hipStream_t s = m->st[i];
     const uint64_t wout = m->par.window_out_len;
     const uint32_t hpw = m->par.hops_per_window;
     RC_HIP(hipSetDevice(dev));
+    hipStream_t s = e->stream;
+    // a share on the root's own device reads and writes the caller's tensors in place (also when the root device is
+    // listed more than once): nothing to copy. rc_multi_set_staging(m, 1) takes the copy path regardless.
+    const bool in_place = !host && dev == root_dev && !m->force_staging;
+    size_t need_in = 0, need_out = 0;
+    if (!in_place)
+        for (const rc_shard &sh : plan) {
+            if (sh.device_index != i || sh.win_count == 0) continue;
+            size_t lo, hi;
+            input_span(m->par, sh.win_first, sh.win_first + sh.win_count, in_len, &lo, &hi);
+            need_in += (size_t)sh.ch_count * (hi - lo);
+            need_out += (size_t)sh.ch_count * (size_t)(sh.win_count * wout);
+        }
+    if (need_in || need_out) {
+        if (int rc = m->d_in[i].reserve(std::max<size_t>(1, need_in) * sizeof(float))) return rc;
+        if (int rc = m->d_out[i].reserve(std::max<size_t>(1, need_out) * sizeof(float))) return rc;
+    }
+    size_t off_in = 0, off_out = 0;
+    struct Deliver {  // host form: the shards go out after all pieces are computed (one pass of the copy workers each)
+        const rc_shard *sh;
+        float *from;
+        size_t n;
+    };
+    std::vector<Deliver> deliver;
     for (const rc_shard &sh : plan) {
         if (sh.device_index != i || sh.win_count == 0) continue;
         const size_t n_sh = (size_t)(sh.win_count * wout);
-        if (is_root && !host) {  // input and output already live here: compute straight into the final place
+        if (in_place) {
             int rc = run_hops(e, src + (size_t)sh.ch_first * src_stride, src_stride, 0, (int64_t)in_len, sh.ch_first,
                               sh.ch_count, (int64_t)(sh.win_first * hpw), (int64_t)(sh.win_count * hpw),
                               dst + (size_t)sh.ch_first * dst_stride + (size_t)(sh.win_first * wout), dst_stride,
@@ -1894,13 +2093,19 @@ int multi_share(rc_multi *m, size_t i, const std::vector<rc_shard> &plan, bool h
         size_t lo, hi;
         input_span(m->par, sh.win_first, sh.win_first + sh.win_count, in_len, &lo, &hi);
         const size_t span = hi - lo;
-        if (int rc = m->d_in[i].reserve(std::max<size_t>(1, (size_t)sh.ch_count * span) * sizeof(float))) return rc;
-        if (int rc = m->d_out[i].reserve((size_t)sh.ch_count * n_sh * sizeof(float))) return rc;
-        float *li = (float *)m->d_in[i].p, *lo_ = (float *)m->d_out[i].p;
-        for (uint32_t c = 0; c < sh.ch_count && span; ++c) {
-            const float *from = host ? src_rows[sh.ch_first + c] + lo : src + (size_t)(sh.ch_first + c) * src_stride + lo;
-            if (host) RC_HIP(hipMemcpyAsync(li + (size_t)c * span, from, span * sizeof(float), hipMemcpyHostToDevice, s));
-            else RC_HIP(hipMemcpyPeerAsync(li + (size_t)c * span, dev, from, root_dev, span * sizeof(float), s));
+        float *li = (float *)m->d_in[i].p + off_in, *lo_ = (float *)m->d_out[i].p + off_out;
+        off_in += (size_t)sh.ch_count * span;
+        off_out += (size_t)sh.ch_count * n_sh;
+        if (span) {
+            if (host) {  // pinned staging slots + copy workers (host_copy), not the runtime's pageable path
+                std::vector<float *> rows(sh.ch_count);
+                for (uint32_t c = 0; c < sh.ch_count; ++c) rows[c] = const_cast<float *>(src_rows[sh.ch_first + c]) + lo;
+                if (int rc = host_copy(e, true, rows.data(), li, span, span, sh.ch_count)) return rc;
+            } else {
+                for (uint32_t c = 0; c < sh.ch_count; ++c)
+                    RC_HIP(hipMemcpyPeerAsync(li + (size_t)c * span, dev, src + (size_t)(sh.ch_first + c) * src_stride + lo,
+                                              root_dev, span * sizeof(float), s));
+            }
         }
         // the local buffer holds samples [lo, hi) of each channel: in_origin = lo, and the samples that exist end at
         // in_len (a window running past it is zero-padded by the engine as in the whole job)
@@ -1908,13 +2113,18 @@ int multi_share(rc_multi *m, size_t i, const std::vector<rc_shard> &plan, bool h
                           (int64_t)(sh.win_first * hpw), (int64_t)(sh.win_count * hpw), lo_, n_sh,
                           (int64_t)(sh.win_first * wout), s, true);
         if (rc) return rc;
-        for (uint32_t c = 0; c < sh.ch_count; ++c) {
-            float *to = host ? dst_rows[sh.ch_first + c] + (size_t)(sh.win_first * wout)
-                             : dst + (size_t)(sh.ch_first + c) * dst_stride + (size_t)(sh.win_first * wout);
-            if (host) RC_HIP(hipMemcpyAsync(to, lo_ + (size_t)c * n_sh, n_sh * sizeof(float), hipMemcpyDeviceToHost, s));
-            else RC_HIP(hipMemcpyPeerAsync(to, root_dev, lo_ + (size_t)c * n_sh, dev, n_sh * sizeof(float), s));
+        if (host) {
+            deliver.push_back(Deliver{&sh, lo_, n_sh});
+        } else {
+            for (uint32_t c = 0; c < sh.ch_count; ++c)
+                RC_HIP(hipMemcpyPeerAsync(dst + (size_t)(sh.ch_first + c) * dst_stride + (size_t)(sh.win_first * wout),
+                                          root_dev, lo_ + (size_t)c * n_sh, dev, n_sh * sizeof(float), s));
         }
-        RC_HIP(hipStreamSynchronize(s));  // (the local buffers are reused by this device's next shard)
+    }
+    for (const Deliver &d : deliver) {
+        std::vector<float *> rows(d.sh->ch_count);
+        for (uint32_t c = 0; c < d.sh->ch_count; ++c) rows[c] = dst_rows[d.sh->ch_first + c] + (size_t)(d.sh->win_first * wout);
+        if (int rc = host_copy(e, false, rows.data(), d.from, d.n, d.n, d.sh->ch_count)) return rc;
     }
     RC_HIP(hipStreamSynchronize(s));
     return check_device_error(e);
@@ -1927,10 +2137,11 @@ int rc_multi_stretch_host(rc_multi *m, const float *const *in, size_t in_len, fl
     const uint64_t total_win = offline_windows(m->par, in_len);
     const size_t n_out = (size_t)(total_win * m->par.window_out_len);
     if (out_cap < n_out) return fail(RC_ECAPACITY, "out_cap %zu < %zu", out_cap, n_out);
+    DeviceRestore restore;
     std::vector<rc_shard> plan(3 * m->eng.size());
     plan.resize(rc_shard_plan(m->cfg.channels, total_win, (uint32_t)m->eng.size(), plan.data(), plan.size()));
     int rc = for_each_device(m, [&](size_t i) {
-        return multi_share(m, i, plan, true, 0, nullptr, 0, in, in_len, nullptr, 0, out, false);
+        return multi_share(m, i, plan, true, 0, nullptr, 0, in, in_len, nullptr, 0, out);
     });
     if (rc == RC_OK && out_len) *out_len = n_out;
     return rc;
@@ -1945,17 +2156,59 @@ int rc_multi_stretch_device(rc_multi *m, uint32_t root, const float *d_in, size_
     const uint64_t total_win = offline_windows(m->par, in_len);
     const size_t n_out = (size_t)(total_win * m->par.window_out_len);
     if (out_cap < n_out) return fail(RC_ECAPACITY, "out_cap %zu < %zu", out_cap, n_out);
-    RC_HIP(hipSetDevice(m->dev[root]));
+    if (m->cfg.channels > 1 && (in_stride < in_len || out_stride < n_out))
+        return fail(RC_EINVAL, "row strides (%zu, %zu) shorter than the rows (%zu, %zu)", in_stride, out_stride, in_len, n_out);
+    DeviceRestore restore;
+    const int root_dev = m->dev[root];
+    if (int rc = check_on_device(in_len ? d_in : nullptr, root_dev, "d_in")) return rc;
+    if (int rc = check_on_device(d_out, root_dev, "d_out")) return rc;
+    RC_HIP(hipSetDevice(root_dev));
     if (hip_stream) RC_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
     std::vector<rc_shard> plan(3 * m->eng.size());
     plan.resize(rc_shard_plan(m->cfg.channels, total_win, (uint32_t)m->eng.size(), plan.data(), plan.size()));
-    const int root_dev = m->dev[root];
     int rc = for_each_device(m, [&](size_t i) {
-        return multi_share(m, i, plan, false, root_dev, d_in, in_stride, nullptr, in_len, d_out, out_stride, nullptr,
-                           i == root);
+        return multi_share(m, i, plan, false, root_dev, d_in, in_stride, nullptr, in_len, d_out, out_stride, nullptr);
     });
     if (rc == RC_OK && out_len) *out_len = n_out;
     return rc;
+} catch (...) {
+    return rc_catch();
+}
+
+int rc_calib_valu(int device, void *hip_stream, uint32_t launches, float *ms_per_launch, float *ns_per_inst) try {
+    if (launches == 0 || (!ms_per_launch && !ns_per_inst)) return fail(RC_EINVAL, "bad argument");
+    DeviceRestore restore;
+    RC_HIP(hipSetDevice(device));
+    hipDeviceProp_t pr{};
+    RC_HIP(hipGetDeviceProperties(&pr, device));
+    const int n_cu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
+    hipStream_t s = (hipStream_t)hip_stream;
+    float *d = nullptr;
+    RC_HIP(hipMalloc((void **)&d, sizeof(float)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Cleanup {
+        float *&d;
+        hipEvent_t &e0, &e1;
+        ~Cleanup() {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            if (d) (void)hipFree(d);
+        }
+    } cleanup{d, e0, e1};
+    RC_HIP(hipEventCreate(&e0));
+    RC_HIP(hipEventCreate(&e1));
+    RC_HIP(rc::launch_calib_valu(d, n_cu, s));  // (code object load, clocks)
+    RC_HIP(hipEventRecord(e0, s));
+    for (uint32_t i = 0; i < launches; ++i) RC_HIP(rc::launch_calib_valu(d, n_cu, s));
+    RC_HIP(hipEventRecord(e1, s));
+    RC_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    RC_HIP(hipEventElapsedTime(&ms, e0, e1));
+    const float per = ms / (float)launches;
+    if (ms_per_launch) *ms_per_launch = per;
+    // per SIMD: 8 workgroups x 4 waves per CU over 4 SIMDs = 8 waves, each CALIB_ITERS x 16 instructions
+    if (ns_per_inst) *ns_per_inst = per * 1.0e6f / (8.0f * (float)rc::CALIB_ITERS * 16.0f);
+    return RC_OK;
 } catch (...) {
     return rc_catch();
 }

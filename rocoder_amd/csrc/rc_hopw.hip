@@ -23,6 +23,11 @@
 namespace rc {
 namespace {
 
+// rc_engine_create lays hann_rot out as [part][Geo<LOG2N>::T][4] (hop_geometry); the kernels below index it with the
+// lane counts they are written for (64 threads; 128 at N = 8192). A build with another RC_PMAX must not pass silently.
+static_assert(Geo<9>::T == 64 && Geo<10>::T == 64 && Geo<11>::T == 64 && Geo<12>::T == 64 && Geo<13>::T == 128,
+              "wave-local kernels: hann_rot part strides assume RC_PMAX = 32");
+
 constexpr int HW_BUF = 1088;                      // exchange buffer, float2 slots (1083 used)
 constexpr int HW_TA = HW_BUF;                     // [65] W_2048^r, r <= 64
 constexpr int HW_TR = HW_TA + 72;                 // [65] W_4096^r, r <= 64 (r = 64: lane 0's second residue, as i W)

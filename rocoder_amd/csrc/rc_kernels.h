@@ -196,6 +196,9 @@ struct ResampleParams {
     uint32_t n_channels, half, samples_needed, window_out_len, f;
 };
 hipError_t launch_resample_slower(const ResampleParams &p, hipStream_t s);
+// box calibration (rc_calib_valu): CALIB_ITERS x 16 packed FMAs per wave, eight waves per SIMD
+constexpr int CALIB_ITERS = 4096;
+hipError_t launch_calib_valu(float *d_out, int n_cu, hipStream_t s);
 // stage 0 = A (forward quarter FFTs), 1 = B (radix-4 + middle + radix-4), 2 = C (inverse quarter FFTs)
 // mode selects stage B's variant (user-kernel path: MODE_FORWARD, host apply(), MODE_RESYNTH)
 hipError_t launch_big(int stage, const BigParams &p, hipStream_t s, HopMode mode = MODE_FUSED);

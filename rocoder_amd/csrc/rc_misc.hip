@@ -459,6 +459,30 @@ hipError_t launch_resample_slower(const ResampleParams &p, hipStream_t s) {
     return hipSuccess;
 }
 
+// Box calibration (rc_calib_valu, measurement support): CALIB_ITERS x 16 independent v_pk_fma_f32 per wave, 256
+// threads x 8 workgroups per CU = eight waves per SIMD, no memory traffic - the instruction the fused kernels are
+// bound by, at the occupancy where its issue rate is flat (tools/valurate.hip is the full table).
+__global__ __launch_bounds__(256) void calib_valu_kernel(float *out, float seed) {
+    v2f pk[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pk[i] = v2f{seed + 0.001f * (float)(threadIdx.x + i), seed};
+    for (int it = 0; it < CALIB_ITERS / 4; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(pk[i]));
+        }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += pk[i].x + pk[i].y;
+    if (acc == 12345.678f) out[0] = acc;  // (never true: keeps the chains alive)
+}
+hipError_t launch_calib_valu(float *d_out, int n_cu, hipStream_t s) {
+    hipLaunchKernelGGL(calib_valu_kernel, dim3((unsigned)n_cu * 8), dim3(256), 0, s, d_out, 1.0f);
+    return hipGetLastError();
+}
+
 hipError_t launch_ola(const OlaParams &p, hipStream_t s, bool tail_only) {
     const dim3 grid((unsigned)p.hop_count, p.n_channels), block(256);
     if (!tail_only) {

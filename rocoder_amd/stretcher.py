@@ -20,7 +20,7 @@ from typing import Callable, List, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import RC_WOULD_BLOCK, RocoderError, check, rc_config, rc_params
+from ._lib import RC_EINVAL, RC_WOULD_BLOCK, RocoderError, check, rc_config, rc_params
 
 
 @dataclass(frozen=True)
@@ -170,6 +170,18 @@ class Engine:
             return None
         return out[: n.value]
 
+    def next_window_view(self, channel: int) -> Optional[np.ndarray]:
+        """The same hand-out without the copy (rc_engine_next_window_view): a read-only array over the engine's
+        pinned block, valid until the next hand-out of this channel. None when the reference would block."""
+        p = C.POINTER(C.c_float)()
+        n = C.c_size_t(0)
+        rc = self._check(self._L.rc_engine_next_window_view(self._h, channel, C.byref(p), C.byref(n)))
+        if rc == RC_WOULD_BLOCK:
+            return None
+        a = np.ctypeslib.as_array(p, shape=(n.value,))
+        a.flags.writeable = False
+        return a
+
     def is_done(self, channel: int) -> bool:
         return bool(self._check(self._L.rc_engine_is_done(self._h, channel)))
 
@@ -278,6 +290,7 @@ class MultiEngine:
         h = C.c_void_p()
         self._check(self._L.rc_multi_create(C.byref(self._cfg), ids, len(device_ids), C.byref(h)))
         self._h = h
+        self.device_ids = [int(d) for d in device_ids]
         self.channels = int(self._cfg.channels)
         self.params = derive_params(**kw)
 
@@ -310,14 +323,25 @@ class MultiEngine:
         assert got.value == n_out
         return out
 
+    def set_staging(self, force: bool):
+        """Diagnostic (rc_multi_set_staging): shares on the root's own device take the copy path of a remote one."""
+        self._check(self._L.rc_multi_set_staging(self._h, 1 if force else 0))
+
     def stretch_tensor(self, x, out=None, root: int = 0):
-        """x, out: torch float32 CUDA tensors on the ROOT device of the list. Blocking."""
+        """x, out: torch float32 CUDA tensors on the ROOT device of the list (device_ids[root]). Blocking."""
         import torch
 
+        if not 0 <= root < len(self.device_ids):
+            raise RocoderError(RC_EINVAL, f"root {root} is not an index of the device list {self.device_ids}")
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        assert x.shape[0] == self.channels, (x.shape, self.channels)
+        assert x.device.index == self.device_ids[root], \
+            f"x lives on cuda:{x.device.index}, the root of the list is cuda:{self.device_ids[root]}"
         n_out = self.output_len(x.shape[1])
         if out is None:
             out = torch.empty((self.channels, n_out), dtype=torch.float32, device=x.device)
+        assert out.device == x.device and out.dtype == torch.float32 and out.dim() == 2
+        assert out.shape[0] == self.channels and out.shape[1] >= n_out and out.stride(1) == 1, (out.shape, out.stride())
         got = C.c_size_t(0)
         s = torch.cuda.current_stream(x.device)
         s.synchronize()

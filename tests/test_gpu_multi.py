@@ -37,10 +37,15 @@ def test_multi_device_equals_one_engine_bit_for_bit(n_dev, N, f, p, ch, L):
     with ra.MultiEngine([0] * n_dev, window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=99) as m:
         got_h = m.stretch_host(x)
         xt = torch.from_numpy(x).cuda()
+        # every listed "device" is the root's own GPU here: by default its shares compute in place...
+        got_ip = m.stretch_tensor(xt, root=n_dev - 1).cpu().numpy()
+        # ... and with forced staging they take a remote device's path: span copy in, compute, shard copy out
+        m.set_staging(True)
         got_d = m.stretch_tensor(xt, root=n_dev - 1).cpu().numpy()
         got_d2 = m.stretch_tensor(xt, root=0).cpu().numpy()  # (buffers of the first call are reused)
     assert got_h.shape == one.shape
     assert np.array_equal(got_h, one)
+    assert np.array_equal(got_ip, one)
     assert np.array_equal(got_d, one)
     assert np.array_equal(got_d2, one)
 
@@ -58,6 +63,41 @@ def test_multi_device_refuses_a_host_kernel_and_a_bad_root():
         with pytest.raises(_lib.RocoderError) as ei:
             m.stretch_tensor(torch.zeros((1, 5000), device="cuda"), root=2)
         assert ei.value.code == _lib.RC_EINVAL
+
+
+def test_multi_device_checks_where_the_tensors_live_and_keeps_the_callers_device():
+    """pointers that are not device memory of the list's root are RC_EINVAL (not garbage or a fault), and
+    the calling thread's current HIP device is what it was."""
+    import ctypes as C
+
+    import torch
+
+    ra = _ra()
+    from rocoder_amd import _lib
+
+    L = _lib.lib()
+    with ra.MultiEngine([0, 0], window_len=1024, factor=2.0, channels=2) as m:
+        x = torch.zeros((2, 5000), device="cuda")
+        n_out = m.output_len(5000)
+        out = torch.empty((2, n_out), device="cuda")
+        host = np.zeros((2, 5000), np.float32)
+        got = C.c_size_t(0)
+        rc = L.rc_multi_stretch_device(m._h, 0, C.c_void_p(host.ctypes.data), 5000, 5000, C.c_void_p(out.data_ptr()),
+                                       n_out, n_out, C.byref(got), None)
+        assert rc == _lib.RC_EINVAL and b"d_in" in L.rc_last_error()
+        rc = L.rc_multi_stretch_device(m._h, 0, C.c_void_p(x.data_ptr()), 5000, 5000, C.c_void_p(host.ctypes.data),
+                                       n_out, n_out, C.byref(got), None)
+        assert rc == _lib.RC_EINVAL and b"d_out" in L.rc_last_error()
+        rc = L.rc_multi_stretch_device(m._h, 0, C.c_void_p(x.data_ptr()), 100, 5000, C.c_void_p(out.data_ptr()),
+                                       n_out, n_out, C.byref(got), None)  # rows overlap
+        assert rc == _lib.RC_EINVAL
+        with pytest.raises(AssertionError):
+            m.stretch_tensor(torch.zeros((3, 5000), device="cuda"))  # channel count
+        with pytest.raises(AssertionError):
+            m.stretch_tensor(x, out=torch.empty((2, n_out - 1), device="cuda"))
+        before = torch.cuda.current_device()
+        m.stretch_tensor(x, out=out)
+        assert torch.cuda.current_device() == before
 
 
 def test_multi_device_from_plain_c(tmp_path):

@@ -18,12 +18,17 @@ with rocoder_amd.Engine(**kw) as e:
     for _ in range(10):
         t0 = time.perf_counter(); e.stretch_tensor(x, out=out); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     res["one_engine_ms"] = round(1e3 * statistics.median(ts), 3)
-for n in (1, 2, 4, 8):
-    with rocoder_amd.MultiEngine([0] * n, **kw) as m:
-        for _ in range(3):
-            m.stretch_tensor(x, out=out)
-        ts = []
-        for _ in range(10):
-            t0 = time.perf_counter(); m.stretch_tensor(x, out=out); ts.append(time.perf_counter() - t0)
-        res[f"multi_{n}x_same_gpu_ms"] = round(1e3 * statistics.median(ts), 3)
+# default: shares on the root's own device compute in place -> what is left is the host side of the sharding (persistent
+# worker threads, one launch per share, one synchronisation per thread). staged: every share takes a remote device's
+# path (span copy in, compute, shard copy out), which on one GPU adds a device-to-device copy of 7/8 of the output.
+for staged in (False, True):
+    for n in (1, 2, 4, 8):
+        with rocoder_amd.MultiEngine([0] * n, **kw) as m:
+            m.set_staging(staged)
+            for _ in range(3):
+                m.stretch_tensor(x, out=out)
+            ts = []
+            for _ in range(10):
+                t0 = time.perf_counter(); m.stretch_tensor(x, out=out); ts.append(time.perf_counter() - t0)
+            res[f"multi_{n}x_same_gpu{'_staged' if staged else ''}_ms"] = round(1e3 * statistics.median(ts), 3)
 print(json.dumps(res))
