@@ -12,6 +12,10 @@ outputs left sharded in HBM; the cost of the one optional collective, the RCCL c
 rank 0, is measured in a second timed region and reported beside it (config.concat); at N > 1 BASELINE
 configs[4] (C5: 8 channels, window 65536) cut over the same ranks is timed as well (config.c5_sharded). Both
 extras run after the main line is complete, under a watchdog, so they can never cost the measurement.
+The metric names a FIXED workload ("16384-win f=8 stereo @1/2/4/8 GPU"), so a second timed region cuts the N = 1
+job itself (L = 26 460 000 per channel, whatever N is) over the N ranks with the same shard plan: config.strong =
+{ms_per_step, value_Msamples_s, ms_per_step_1gpu (the same job on this rank's GPU alone, same run),
+efficiency_vs_1gpu}. `scaling` stays "weak" for `value`; config.strong.scaling says "strong".
 
 The same JSON line carries
   roofline     — the dominant kernel (the N = 16384 fused hop kernel) priced on SURVEY §8(d4)'s
@@ -47,6 +51,9 @@ CONCAT_TIMEOUT_S = float(os.environ.get("ROCODER_BENCH_CONCAT_TIMEOUT", "120")) 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 LDS_READ_PEAK_GBS = 150e3    # MI355X_MICROARCH.md §LDS: ds_read_b64/b128, every CU streaming
 LDS_WRITE_PEAK_GBS = 45e3    # same: 38-51 TB/s for ds_write_b32..b128
+# rc_calib_valu on the reference box of profiles/README.md's normalised table (ns per packed-FMA wave instruction per
+# SIMD, eight waves per SIMD): kernel_ms_normalised = kernel_ms * REF / this box's value
+BOX_CALIB_REF_NS = 1.70
 
 
 def synth_on_device(torch, device, channels, length):
@@ -269,6 +276,67 @@ def main():
     note(f"timed region done: {dt:.4f} s")
     dt = max_over_ranks(dt)
 
+    # ---- box calibration: a fixed pure-VALU kernel on the same stream right after the timed
+    # steps, ~50 ms, so that a slow box shows in the JSON line itself
+    calib = None
+    try:
+        import ctypes as C
+
+        ms_l, ns_i = C.c_float(0), C.c_float(0)
+        rc = _lib.lib().rc_calib_valu(dev_index, C.c_void_p(stream.cuda_stream), 48, C.byref(ms_l), C.byref(ns_i))
+        if rc == 0:
+            calib = {"ms_per_launch": float(ms_l.value), "ns_per_inst": float(ns_i.value)}
+    except Exception as ex:  # noqa: BLE001
+        calib = {"error": f"{type(ex).__name__}: {ex}"[:200]}
+
+    # ---- strong scaling of the metric's fixed job: the N = 1 job cut N ways
+    strong = None
+    if world > 1:
+        try:
+            with torch.cuda.stream(stream):
+                xf = x[:, :L_IN]
+                n_out_f = eng.output_len(L_IN)
+                nwin_f = n_out_f // wout
+                plan_f = shard_plan(CHANNELS, nwin_f, world)
+                mine_f = [s for s in plan_f if s.rank == rank]
+                comp_f = engine_compute(eng, xf)
+                bufs_f = {s: torch.empty((s.ch_count, s.win_count * wout), dtype=torch.float32, device=device)
+                          for s in mine_f}
+                full_f = torch.empty((CHANNELS, n_out_f), dtype=torch.float32, device=device)
+                one_f = [s for s in shard_plan(CHANNELS, nwin_f, 1)]
+
+                def timed(fn, k):
+                    for _ in range(3):
+                        fn()
+                    barrier()
+                    t = time.perf_counter()
+                    for _ in range(k):
+                        fn()
+                    barrier()
+                    return max_over_ranks(time.perf_counter() - t) / k
+
+                ks = max(args.steps, 20)
+                t_n = timed(lambda: [comp_f(s, out=bufs_f[s]) for s in mine_f], ks)
+                # the same job on ONE GPU, in this run: every rank does the whole job on its own GPU (max over ranks)
+                t_1 = timed(lambda: [comp_f(s, out=full_f[s.ch_first:s.ch_first + s.ch_count]) for s in one_f], ks)
+                strong = {
+                    "scaling": "strong",
+                    "workload": f"BASELINE configs[1] at its own size (L={L_IN}/ch), cut over {world} rank(s) by shard_plan",
+                    "steps": ks,
+                    "ms_per_step": round(t_n * 1e3, 4),
+                    "value_Msamples_s": round(float(n_out_f) * CHANNELS / t_n / 1e6, 1),
+                    "ms_per_step_1gpu": round(t_1 * 1e3, 4),
+                    "efficiency_vs_1gpu": round(t_1 / (world * t_n), 4),
+                    "hops_per_rank": sum(s.ch_count * s.win_count for s in mine_f) * eng.params.hops_per_window,
+                    "plan": [(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan_f],
+                    "note": "outputs left sharded in HBM, no collective; wall time between barriers, max over ranks, "
+                            "one kernel launch per shard per step (the per-step host cost is inside)",
+                }
+                del bufs_f, full_f
+        except Exception as ex:  # noqa: BLE001
+            strong = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+        note(f"strong leg: {strong}")
+
     extras = {}
     concat = None
     if not args.no_extras:
@@ -349,6 +417,16 @@ def main():
                              f"with the pipes 100 % busy would reach frac {roof['frac_at_full_valu_occupancy']} - the "
                              "0.40 target needs fewer VALU cycles per hop (the frozen phase spec's hash + sincos, the "
                              "butterflies at 1.5 packed FMAs per point and stage), not more overlap")
+        roof["counters_box"] = "builder"  # traffic / valu_busy come from the committed PMC summary, not from this box
+        if calib and "ns_per_inst" in calib:
+            # kernel_ms scaled to the reference box speed: boxes of the pool differ by +-3..5 % on the same binary
+            roof["box_calib_ns"] = round(calib["ns_per_inst"], 4)
+            roof["box_calib_ms_per_launch"] = round(calib["ms_per_launch"], 4)
+            roof["box_calib_ref_ns"] = BOX_CALIB_REF_NS
+            roof["kernel_ms_normalised"] = round(kernel_ms_median * BOX_CALIB_REF_NS / calib["ns_per_inst"], 4)
+            roof["frac_normalised"] = round(achieved / HBM_PEAK_GBS * calib["ns_per_inst"] / BOX_CALIB_REF_NS, 4)
+        elif calib:
+            roof["box_calib_error"] = calib.get("error")
         if "copy_GBs" in extras:
             roof["measured_copy_GBs"] = round(extras["copy_GBs"], 1)
             roof["frac_measured_peak"] = round(achieved / extras["copy_GBs"], 4)
@@ -381,6 +459,13 @@ def main():
             },
             "roofline": roof,
         }
+        if strong is None and world == 1:  # at N = 1 the main line IS the fixed job
+            strong = {"scaling": "strong", "workload": f"BASELINE configs[1] at its own size (L={L_IN}/ch): the main line",
+                      "steps": args.steps, "ms_per_step": round(dt / args.steps * 1e3, 4),
+                      "value_Msamples_s": round(value, 1), "ms_per_step_1gpu": round(dt / args.steps * 1e3, 4),
+                      "efficiency_vs_1gpu": 1.0}
+        if strong:
+            res["config"]["strong"] = strong
         if "e2e_pcie_Msamples_s" in extras:
             res["config"]["e2e_pcie_Msamples_s"] = round(extras["e2e_pcie_Msamples_s"], 1)
         if world == 1 and not args.no_cpu_baseline:

@@ -207,11 +207,9 @@ Audio read_wav(FILE *f) {
     return a;
 }
 
-void write_wav_f32(const std::string &path, const Audio &a) {  // audio_files.rs:68-81,203-226
-    FILE *f = fopen(path.c_str(), "wb");
-    if (!f) throw std::runtime_error("cannot create " + path);
-    const uint32_t ch = a.spec.channels, rate = a.spec.sample_rate;
-    const uint64_t frames = a.data.empty() ? 0 : a.data[0].size();
+// 32-bit float WAV as hound writes it (audio_files.rs:68-81,203-226): WAVE_FORMAT_EXTENSIBLE header + interleaved frames
+void write_wav_header(FILE *f, const AudioSpec &spec, uint64_t frames) {
+    const uint32_t ch = spec.channels, rate = spec.sample_rate;
     const uint64_t data_bytes = frames * ch * 4;
     auto w32 = [&](uint32_t v) { fwrite(&v, 4, 1, f); };
     auto w16 = [&](uint16_t v) { fwrite(&v, 2, 1, f); };
@@ -234,6 +232,14 @@ void write_wav_f32(const std::string &path, const Audio &a) {  // audio_files.rs
     fwrite(guid_float, 1, 16, f);
     fwrite("data", 1, 4, f);
     w32((uint32_t)std::min<uint64_t>(0xFFFFFFFFu, data_bytes));
+}
+
+void write_wav_f32(const std::string &path, const Audio &a) {
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot create " + path);
+    const uint32_t ch = a.spec.channels;
+    const uint64_t frames = a.data.empty() ? 0 : a.data[0].size();
+    write_wav_header(f, a.spec, frames);
     std::vector<float> row((size_t)ch * 4096);
     for (uint64_t i0 = 0; i0 < frames; i0 += 4096) {
         const uint64_t k = std::min<uint64_t>(4096, frames - i0);
@@ -244,12 +250,53 @@ void write_wav_f32(const std::string &path, const Audio &a) {  // audio_files.rs
     fclose(f);
 }
 
+// The same file written as the windows arrive (README.md:74 "stream output to disk instead of RAM", src/main.rs:197-203
+// collects the whole AudioBus first): the header goes out with the sizes still zero, every batch of windows that all
+// channels have delivered is interleaved and appended, and the two size fields are patched at the end - byte for
+// byte the file write_wav_f32 writes, with the resident set bounded by the queue depth instead of the output length.
+struct WavStreamWriter {
+    FILE *f = nullptr;
+    AudioSpec spec;
+    uint64_t frames = 0;
+    std::vector<float> row;
+    WavStreamWriter(const std::string &path, const AudioSpec &sp) : spec(sp) {
+        f = fopen(path.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot create " + path);
+        write_wav_header(f, spec, 0);
+    }
+    ~WavStreamWriter() {
+        if (f) fclose(f);
+    }
+    // chans[c]: the next samples of channel c (equal lengths)
+    void append(const std::vector<const float *> &chans, size_t n) {
+        const uint32_t ch = spec.channels;
+        row.resize((size_t)ch * std::min<size_t>(n, 4096));
+        for (size_t i0 = 0; i0 < n; i0 += 4096) {
+            const size_t k = std::min<size_t>(4096, n - i0);
+            for (size_t i = 0; i < k; ++i)
+                for (uint32_t c = 0; c < ch; ++c) row[i * ch + c] = chans[c][i0 + i];  // interleave
+            if (fwrite(row.data(), 4, k * ch, f) != k * ch) throw std::runtime_error("write failed (disk full?)");
+        }
+        frames += n;
+    }
+    void finish() {
+        if (fseek(f, 0, SEEK_SET) != 0) throw std::runtime_error("cannot seek in the output file");
+        write_wav_header(f, spec, frames);
+        if (fclose(f) != 0) {
+            f = nullptr;
+            throw std::runtime_error("closing the output file failed");
+        }
+        f = nullptr;
+    }
+};
+
 // ------------------------------------------------------------------ bounded(cap) channel of windows
 struct WindowQueue {
     explicit WindowQueue(size_t cap) : cap(std::max<size_t>(1, cap)) {}
     void send(std::vector<float> v) {
         std::unique_lock<std::mutex> lk(m);
-        cv_space.wait(lk, [&] { return q.size() < cap; });
+        cv_space.wait(lk, [&] { return q.size() < cap || abandoned; });
+        if (abandoned) return;
         q.push_back(std::move(v));
         cv_item.notify_one();
     }
@@ -257,6 +304,12 @@ struct WindowQueue {
         std::lock_guard<std::mutex> lk(m);
         closed = true;
         cv_item.notify_all();
+    }
+    void abandon() {  // the Receiver was dropped: pending and later sends are discarded (never block the sender)
+        std::lock_guard<std::mutex> lk(m);
+        abandoned = true;
+        q.clear();
+        cv_space.notify_all();
     }
     // 0 = got item, 1 = timeout, 2 = disconnected
     int recv_timeout(std::vector<float> *out, std::chrono::milliseconds to) {
@@ -279,7 +332,7 @@ struct WindowQueue {
     std::mutex m;
     std::condition_variable cv_item, cv_space;
     std::deque<std::vector<float>> q;
-    bool closed = false;
+    bool closed = false, abandoned = false;
 };
 
 // ------------------------------------------------------------------ src/hotswapper.rs + fft.rs:76-108
@@ -523,6 +576,56 @@ Audio into_audio(const AudioSpec &spec, std::vector<std::shared_ptr<WindowQueue>
     return a;
 }
 
+// The same drain, written out as it arrives: a window goes to the file as soon as every channel has delivered its
+// next one (the processor sends them round robin, src/stretcher_processor.rs:63-70). Returns the frames written.
+uint64_t drain_to_wav(WavStreamWriter &w, std::vector<std::shared_ptr<WindowQueue>> &chs) {
+    const size_t C = chs.size();
+    std::vector<std::deque<std::vector<float>>> pend(C);
+    std::vector<size_t> used(C, 0);  // samples of pend[c].front() already written
+    std::vector<bool> closed(C, false);
+    auto flush = [&] {
+        for (;;) {
+            size_t n = SIZE_MAX;
+            for (size_t c = 0; c < C; ++c) n = std::min(n, pend[c].empty() ? 0 : pend[c].front().size() - used[c]);
+            if (n == 0 || n == SIZE_MAX) return;
+            std::vector<const float *> rows(C);
+            for (size_t c = 0; c < C; ++c) rows[c] = pend[c].front().data() + used[c];
+            w.append(rows, n);
+            for (size_t c = 0; c < C; ++c) {
+                used[c] += n;
+                if (used[c] == pend[c].front().size()) {
+                    pend[c].pop_front();
+                    used[c] = 0;
+                }
+            }
+        }
+    };
+    for (;;) {
+        size_t disconnected = 0;
+        for (size_t i = 0; i < C; ++i) {
+            if (closed[i]) {
+                disconnected++;
+                continue;
+            }
+            if (pend[i].size() >= 4) continue;  // this channel is ahead: let the others catch up first
+            std::vector<float> chunk;
+            const int rc = chs[i]->recv_timeout(&chunk, std::chrono::milliseconds(5));
+            if (rc == 0) pend[i].push_back(std::move(chunk));
+            else if (rc == 2) {
+                closed[i] = true;
+                disconnected++;
+            }
+        }
+        flush();
+        if (disconnected == C) break;
+        bool stuck = true;  // every open channel is waiting on a closed, empty one: nothing more can pair up
+        for (size_t i = 0; i < C; ++i)
+            if (!closed[i] && pend[i].size() < 4) stuck = false;
+        if (stuck) break;
+    }
+    return w.frames;
+}
+
 struct Opt {  // src/main.rs:27-122
     size_t window_len = 16384;
     uint64_t buffer_ms = 1000;
@@ -736,13 +839,24 @@ int run(int argc, char **argv) {
     StretcherProcessor proc;
     auto bus = proc.make(std::move(stretchers), 64);
     proc.start();
-    // handle_result (src/main.rs:190-211)
-    Audio out = into_audio(spec, bus, expected_total_samples + o.window_len);
+    // handle_result (src/main.rs:190-211). ROCODER_CLI_COLLECT=1 keeps the reference's order (collect the whole bus in
+    // memory, then write): the A/B partner of the streamed file in tests/test_gpu_cli.py
+    if (getenv("ROCODER_CLI_COLLECT")) {
+        Audio out = into_audio(spec, bus, expected_total_samples + o.window_len);
+        proc.join();
+        if (!proc.error.empty()) throw std::runtime_error(proc.error);
+        lap("stretch");
+        write_wav_f32(*o.output, out);
+        lap("write output");
+        return 0;
+    }
+    WavStreamWriter wav(*o.output, spec);
+    drain_to_wav(wav, bus);
+    for (auto &q : bus) q->abandon();  // (only matters after a `stuck` exit: the processor must not block on a full queue)
     proc.join();
     if (!proc.error.empty()) throw std::runtime_error(proc.error);
-    lap("stretch");
-    write_wav_f32(*o.output, out);
-    lap("write output");
+    wav.finish();
+    lap("stretch+write");
     return 0;
 }
 

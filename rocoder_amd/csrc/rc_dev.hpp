@@ -196,8 +196,19 @@ __device__ __forceinline__ uint32_t phase_hash_x(uint32_t x) {
     return x;
 }
 __device__ __forceinline__ float phase_rev_lower(uint32_t h) { return __uint_as_float(0x3F000000u | (h >> 9)); }
+#ifndef RC_MAD16
+#define RC_MAD16 1
+#endif
 __device__ __forceinline__ float phase_rev_upper(uint32_t h) {
+#if RC_MAD16
+    // (h & 0xFFFF) * 128 + 0x3F000000 in one instruction: v_mad_u32_u16 multiplies the LOW HALVES of its first two
+    // operands (no mask, no shift), the addend is the inline constant 0.5; the fields do not overlap, so + is |
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, 0.5" : "=v"(r) : "v"(h), "s"(128u));
+    return __uint_as_float(r);
+#else
     return __uint_as_float(0x3F000000u | ((h & 0xFFFFu) << 7));
+#endif
 }
 // counter x = c * mul + k0 of c < M: (-cos, -sin) of bin c (lo*) and of bin c + M (up*)
 __device__ __forceinline__ void phase_ncs2_x(uint32_t x, float &lo_nc, float &lo_ns, float &up_nc,

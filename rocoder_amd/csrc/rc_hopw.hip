@@ -18,6 +18,9 @@
 //     ds_write_b64 groups and the 32-lane ds_read_b64 groups
 // 168 VGPRs and 12 KB of LDS per wave: three waves per SIMD. The first hop of a run is recomputed for its tail (no
 // seam hand-over); a caller-supplied window, pitch != 1 ... all take this kernel except a non-default window (generic).
+// (v_mad_u32_u16 for the upper phase mantissa, rc_dev.hpp: -1.2 % on hop4_kernel, but +1..3 % on the 512 / 1024 / 2048
+// kernels of this file and flat at 4096 / 8192 - same-box A/B, profiles/README.md round 4: not used here)
+#define RC_MAD16 0
 #include "rc_dit.hpp"
 
 namespace rc {

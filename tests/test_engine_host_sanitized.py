@@ -1,0 +1,31 @@
+"""CPU tests (-m "not gpu"): the engine's HOST code (rocoder_amd/csrc/rc_engine.cpp) built host-only over the HIP
+stub (tests/c/hip_stub.cpp: device memory is host memory, kernels compute nothing) and driven through the C-ABI by
+tests/c/engine_host_driver.cpp under AddressSanitizer + UndefinedBehaviorSanitizer and under ThreadSanitizer
+(rocoder_amd/csrc/host/sanitize.mk). GPU ASan / XNACK are not available on this pool; this covers what they would
+not: the worker pools, the pinned three-set pipeline, rc_multi's persistent workers, the streaming seam."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HOST = os.path.join(ROOT, "rocoder_amd", "csrc", "host")
+BIN = os.path.join(ROOT, "rocoder_amd", "bin")
+
+
+def _build(target):
+    subprocess.run(["make", "-s", "-f", "sanitize.mk", f"../../bin/{target}"], cwd=HOST, check=True, timeout=600)
+    return os.path.join(BIN, target)
+
+
+@pytest.mark.parametrize("target,env,marker", [
+    ("engine_asan", {"ASAN_OPTIONS": "detect_leaks=1", "UBSAN_OPTIONS": "print_stacktrace=1"}, "Sanitizer"),
+    ("engine_tsan", {"TSAN_OPTIONS": "halt_on_error=0:second_deadlock_stack=1"}, "WARNING: ThreadSanitizer"),
+])
+def test_engine_host_code_is_clean_under_sanitizers(target, env, marker):
+    exe = _build(target)
+    r = subprocess.run([exe], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+    assert marker not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.stdout.startswith("OK engine host driver")

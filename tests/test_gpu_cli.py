@@ -65,6 +65,30 @@ def test_cli_devices_list_writes_the_same_file(tmp_path, extra):
     assert len(outs[0]) > 44 + 3 * 4 * 150000
 
 
+def test_cli_streams_the_output_file_with_bounded_memory(tmp_path):
+    """README.md:74 / SURVEY f1: the output is written as the windows arrive (header first, sizes patched at the end),
+    byte for byte the file of the collect-then-write order (src/main.rs:197-203, ROCODER_CLI_COLLECT=1), and the
+    process no longer holds the output: 300 s of mono at factor 8 is 423 MB of samples."""
+    x = onp.synth_input(0, 44100 * 300)[None]
+    wav = str(tmp_path / "in.wav")
+    write_wav(wav, x, 44100, "f32")
+    files, peak = {}, {}
+    for name, env in (("stream", {}), ("collect", {"ROCODER_CLI_COLLECT": "1"})):
+        out = str(tmp_path / f"{name}.wav")
+        p = subprocess.Popen([CLI, "-i", wav, "-o", out, "-w", "16384", "-f", "8", "--seed", "3"],
+                             env=dict(os.environ, **env), stderr=subprocess.PIPE)
+        _, status, ru = os.wait4(p.pid, 0)
+        assert status == 0, p.stderr.read()
+        p.stderr.close()
+        p.returncode = 0  # (reaped by wait4 above)
+        peak[name] = ru.ru_maxrss * 1024  # Linux: KiB
+        files[name] = out
+    a, b = open(files["stream"], "rb").read(), open(files["collect"], "rb").read()
+    assert len(a) > 400e6 and a == b
+    del a, b
+    assert peak["collect"] - peak["stream"] > 300e6, peak
+
+
 def test_cli_devices_refuses_host_kernels(tmp_path):
     x = np.stack([onp.synth_input(c, 20000) for c in range(2)])
     wav, out, src = str(tmp_path / "in.wav"), str(tmp_path / "o.wav"), str(tmp_path / "k.c")

@@ -4,10 +4,14 @@
 #      tests/test_cli_host.py (duration grammar, WAV decoding incl. the 230-file hostile corpus, flags)
 #   2. ThreadSanitizer build over tests/c/stub_engine.c (computes nothing): file-to-file runs that exercise the
 #      StretcherProcessor thread, the bounded WindowQueues, the AudioBus drain and the kernel hot-swap watcher
-# usage: tools/run_sanitizers.sh [log]      (default log: profiles/r03_sanitizers.txt)
+#   3. the ENGINE's own host code (rc_engine.cpp) built host-only over tests/c/hip_stub.cpp (device memory = host
+#      memory, kernels compute nothing) and driven by tests/c/engine_host_driver.cpp: once with ASan + UBSan, once with
+#      TSan - worker pools, the three-set pinned pipeline of the frequency-kernel path, rc_multi's persistent
+#      workers on {0,0,0} / {0,1,2} / eight entries, the streaming seam pushed and pulled from different threads
+# usage: tools/run_sanitizers.sh [log]      (default log: profiles/r04_sanitizers.txt)
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-LOG=${1:-$ROOT/profiles/r03_sanitizers.txt}
+LOG=${1:-$ROOT/profiles/r04_sanitizers.txt}
 cd "$ROOT"
 {
 echo "# host sanitizer runs, $(date -u +%Y-%m-%dT%H:%MZ), $(g++ --version | head -1)"
@@ -33,5 +37,17 @@ run -i "$T/in2.wav" -o "$T/o2.wav" -w 16384 -f 8 -b 0.05
 run -i "$T/in5.wav" -o "$T/o3.wav" -w 512 -f 1 --rotate-channels -s 0.5 -d 2
 run -i "$T/in2.wav" -o "$T/o4.wav" -w 2048 -f 2 --freq-kernel "$T/k.c"
 rm -rf "$T"
+echo "## 3. the engine's host code over the HIP stub (tests/c/hip_stub.cpp + engine_host_driver.cpp)"
+echo "+ engine_asan (ASan + UBSan, leak detection on)"
+ASAN_OPTIONS=detect_leaks=1 UBSAN_OPTIONS=print_stacktrace=1 "$ROOT/rocoder_amd/bin/engine_asan" > "$ROOT/.san_out.txt" 2>&1; rc=$?
+tail -1 "$ROOT/.san_out.txt" | sed 's/^/  /'; echo "  exit $rc"
+[ $rc -ne 0 ] || grep -q "Sanitizer\|runtime error" "$ROOT/.san_out.txt" && { [ $rc -ne 0 ] && fail=1; grep -q "Sanitizer\|runtime error" "$ROOT/.san_out.txt" && { fail=1; head -40 "$ROOT/.san_out.txt"; }; }
+echo "+ engine_tsan"
+TSAN_OPTIONS=halt_on_error=0:second_deadlock_stack=1 "$ROOT/rocoder_amd/bin/engine_tsan" > "$ROOT/.san_out.txt" 2>&1; rc=$?
+grep -c "WARNING: ThreadSanitizer" "$ROOT/.san_out.txt" | sed 's/^/  ThreadSanitizer warnings: /'
+tail -1 "$ROOT/.san_out.txt" | sed 's/^/  /'; echo "  exit $rc"
+[ $rc -ne 0 ] && fail=1
+grep -q "WARNING: ThreadSanitizer" "$ROOT/.san_out.txt" && { fail=1; grep -A12 "WARNING: ThreadSanitizer" "$ROOT/.san_out.txt" | head -60; }
+rm -f "$ROOT/.san_out.txt"
 [ $fail -eq 0 ] && echo "RESULT: clean" || echo "RESULT: FINDINGS (above)"
 } 2>&1 | tee "$LOG"
