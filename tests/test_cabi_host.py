@@ -179,3 +179,106 @@ def test_abi_struct_layout_matches_the_committed_table_and_the_ctypes_mirror(tmp
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for fname, (off, size) in ((k, v) for k, v in committed["rc_config"].items() if k != "sizeof"):
         assert f"| `{fname}` | {off} | {size} |" in text, f"INTEGRATION.md's rc_config table lacks {fname} @ {off}"
+
+
+# ------------------------------------------------------------------ INTEGRATION.md's Rust stub, checked without rustc
+_RUST_SCALARS = {"u8": (1, 1), "i8": (1, 1), "u16": (2, 2), "i16": (2, 2), "u32": (4, 4), "i32": (4, 4), "f32": (4, 4),
+                 "u64": (8, 8), "i64": (8, 8), "f64": (8, 8), "usize": (8, 8), "isize": (8, 8), "c_int": (4, 4),
+                 "c_char": (1, 1), "RcFreqKernel": (8, 8)}  # Option<extern "C" fn> is pointer-sized (null = None)
+
+
+def _rust_blocks():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rust = "\n".join(re.findall(r"```rust\n(.*?)```", text, flags=re.S))
+    return re.sub(r"//[^\n]*", "", rust)
+
+
+def _rust_struct_layout(rust, name):
+    """repr(C): fields in declaration order, each at the next multiple of its alignment; size rounded up to the
+    largest alignment (x86-64 / aarch64 LP64: pointers and usize are 8 bytes)."""
+    m = re.search(r"#\[repr\(C\)\]\s*pub struct %s\s*\{(.*?)\}" % name, rust, flags=re.S)
+    assert m, f"no #[repr(C)] struct {name} in INTEGRATION.md"
+    off, max_al, out = 0, 1, {}
+    for fname, ty in re.findall(r"pub\s+(\w+)\s*:\s*([^,}]+?)\s*(?:,|$)", m.group(1).strip() + ","):
+        ty = ty.strip()
+        size, al = (8, 8) if ty.startswith("*") else _RUST_SCALARS[ty]
+        off = (off + al - 1) // al * al
+        out[fname] = [off, size]
+        off += size
+        max_al = max(max_al, al)
+    out["sizeof"] = [(off + max_al - 1) // max_al * max_al, max_al]
+    return out
+
+
+def _c_type_to_rust(t):
+    """`const float *const *` -> `*const *const f32` ... (pointers read right to left)."""
+    t = " ".join(t.replace("*", " * ").split())
+    base_map = {"float": "f32", "int": "c_int", "void": "c_void", "char": "c_char", "size_t": "usize",
+                "uint64_t": "u64", "uint32_t": "u32", "int32_t": "i32", "uint16_t": "u16", "rc_config": "RcConfig",
+                "rc_params": "RcParams", "rc_engine": "RcEngine", "rc_multi": "RcMulti", "rc_shard": "RcShard"}
+    toks = t.split()
+    # base type = the tokens before the first '*', minus const
+    i = toks.index("*") if "*" in toks else len(toks)
+    base_const = "const" in toks[:i]
+    base = [x for x in toks[:i] if x != "const"]
+    assert len(base) == 1, t
+    rust = base_map[base[0]]
+    # each '*' (with an optional following const, which qualifies that pointer level) wraps what is to its left
+    pointee_const = base_const
+    j = i
+    while j < len(toks):
+        assert toks[j] == "*", t
+        rust = ("*const " if pointee_const else "*mut ") + rust
+        pointee_const = j + 1 < len(toks) and toks[j + 1] == "const"
+        j += 2 if pointee_const else 1
+    return rust
+
+
+def _header_prototypes():
+    h = open(os.path.join(ROOT, "include", "rocoder_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"^([A-Za-z_][\w \*]*?)\b(rc_\w+)\s*\(([^;{]*?)\)\s*;", h, flags=re.M | re.S):
+        params = []
+        args = " ".join(args.split())
+        if args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                ty = re.sub(r"\b\w+$", "", a).strip()  # drop the parameter name
+                params.append(_c_type_to_rust(ty))
+        r = ret.strip()
+        protos[name] = (None if r == "void" else _c_type_to_rust(r), params)
+    return protos
+
+
+def test_integration_md_rust_stub_matches_the_header():
+    """the reference-side binding cannot be compiled here (no rustc), but
+    its text can be held to the C side: (a) the #[repr(C)] structs, laid out by the repr(C) rules, reproduce the table
+    the C compiler printed (tests/golden/abi_layout.json); (b) the extern "C" block declares exactly the functions of
+    include/rocoder_hip.h, with the header's argument and return types."""
+    import json
+
+    rust = _rust_blocks()
+    committed = json.load(open(os.path.join(ROOT, "tests", "golden", "abi_layout.json")))
+    for rname, cname in (("RcConfig", "rc_config"), ("RcParams", "rc_params"), ("RcShard", "rc_shard")):
+        got = _rust_struct_layout(rust, rname)
+        assert list(got) == [k for k in committed[cname] if k != "sizeof"] + ["sizeof"], (rname, list(got))
+        assert got == {**{k: v for k, v in committed[cname].items() if k != "sizeof"}, "sizeof": committed[cname]["sizeof"]}, rname
+    # the kernel callback type
+    m = re.search(r"pub type RcFreqKernel = Option<\s*unsafe extern \"C\" fn\((.*?)\)\s*->\s*c_int>;", rust, flags=re.S)
+    assert m
+    cb = [a.split(":")[1].strip() for a in " ".join(m.group(1).split()).split(",")]
+    assert cb == ["u64", "*const f32", "*mut f32", "usize", "*mut c_void"]
+    # the extern block
+    ext = re.search(r"extern \"C\" \{(.*?)\n\}", rust, flags=re.S)
+    assert ext
+    fns = {}
+    for name, args, ret in re.findall(r"pub fn (\w+)\((.*?)\)\s*(?:->\s*([^;]+?))?\s*;", ext.group(1), flags=re.S):
+        args = " ".join(args.split())
+        params = [a.split(":", 1)[1].strip() for a in args.split(",")] if args else []
+        fns[name] = (ret.strip() if ret else None, params)
+    protos = _header_prototypes()
+    assert sorted(fns) == sorted(protos), (sorted(set(protos) - set(fns)), sorted(set(fns) - set(protos)))
+    assert sorted(protos) == _header_functions()
+    for name in protos:
+        assert fns[name] == protos[name], (name, fns[name], protos[name])

@@ -16,9 +16,20 @@ x = (torch.rand((2, 13_230_000), device=dev) - 0.5)
 res = {}
 stream = torch.cuda.Stream(dev)
 with torch.cuda.stream(stream):
-    for N in (512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 12000, 24000):
-        xs = x if N >= 512 and (N & (N - 1)) == 0 else x[:, :200_000].contiguous()
-        e = rocoder_amd.Engine(window_len=N, factor=8.0, channels=2, seed=1)
+    # "t" rows: a caller-supplied window (hanning ** 1.5: not the default, so the table-window kernels run -
+    # hop2_kernel at 16384, the generic hop_kernel below)
+    for N in (64, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 12000, 24000, "16384t", "4096t", "1024t"):
+        table = isinstance(N, str)
+        tag = N
+        N = int(N[:-1]) if table else N
+        short = not (N >= 64 and (N & (N - 1)) == 0)
+        xs = x[:, :200_000].contiguous() if short else (x[:, :2_000_000].contiguous() if N < 512 else x)
+        kw = {}
+        if table:
+            import numpy as np
+            w = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(N) / (N - 1))) ** 1.5
+            kw["window"] = w.astype(np.float32)
+        e = rocoder_amd.Engine(window_len=N, factor=8.0, channels=2, seed=1, **kw)
         out = torch.empty((2, e.output_len(xs.shape[1])), device=dev)
         e.stretch_tensor(xs, out=out)
         t0 = time.perf_counter()
@@ -31,7 +42,7 @@ with torch.cuda.stream(stream):
         stream.synchronize()
         ms = statistics.median(e.kernel_times(6))
         _, hops, launches = e.last_kernel_stats()
-        res[f"N{N}"] = dict(kernel_ms=round(ms, 3), hops=hops, launches=launches, in_samples=xs.shape[1],
+        res[f"N{tag}"] = dict(kernel_ms=round(ms, 3), hops=hops, launches=launches, in_samples=xs.shape[1],
                             out_gsamples_s=round(out.numel() / ms / 1e6, 1),
                             frac_hbm_read=round(hops * 4.0 * N / ms / 1e6 / 8000.0, 4))
         e.close()
