@@ -13,9 +13,8 @@ namespace {
 //                         (and tau + 512, RES - 512 - tau for R = 64), RES = 2^(b+5), so every (j, M - j) bin
 //                         pair sits in one thread and the middle stage runs in registers as in hop4_kernel
 //   I1 / I2 / I3 mirror them (4, 5 and b stages); the synthesis window and the two-term overlap-add follow
-//   in registers (R = 32) - for R = 64 the carried tail y_{k-1}[H..] does not fit the register file next to
-//   128 data registers and travels through a per-workgroup scratch of 128 KiB (written and re-read by the
-//   same CU one hop later: L2 / Infinity-Cache traffic, not HBM).
+//   in registers: the thread that owns head sample q owns tail sample q + H, so the carried tail y_{k-1}[H..]
+//   never leaves the thread (R = 64: 27 of its 32 pairs in registers, the last 5 in LDS; no global scratch).
 // Exchanges go through one 16 400-element LDS buffer (131 KB: one workgroup = 8 waves per CU), a single
 // round for R = 32, two rounds of 32 registers per thread for R = 64.
 struct W64Tab {
@@ -49,9 +48,6 @@ __device__ constexpr HannK64 HANN_E15 = make_hann_k64(HANN_ENV_AMP, 16384, 16);
 __device__ constexpr HannK64 HANN_W16 = make_hann_k64(0.5, 65536, 64);
 __device__ constexpr HannK64 HANN_E16 = make_hann_k64(HANN_ENV_AMP, 32768, 32);
 
-#ifndef RC_B4_STAGESB
-#define RC_B4_STAGESB 0
-#endif
 // dit_stages for up to 64 registers: 64th-root constants, otherwise the same arithmetic
 // One DIT stage with a runtime base twiddle, twiddle by twiddle: tw = base W_64^kidx serves the butterflies with
 // c = cc (as it is) and c = cc + nc (rotated by -i), then dies - one live twiddle instead of NREG / 4. Every loop
@@ -82,7 +78,6 @@ template <int NREG, int S_LO, int S_HI, int REG_LO, bool CONJ, int S = S_LO>
 __device__ __forceinline__ void lean_stages(v2f (&v)[NREG], const v2f (&bases)[S_HI - S_LO + 1]) {
     if constexpr (S <= S_HI) {
         lean_stage<NREG, S - REG_LO, CONJ>(v, bases[S - S_LO]);
-        if (RC_B4_STAGESB) __builtin_amdgcn_sched_barrier(0);  // stages do not overlap (their temporaries would add up)
         lean_stages<NREG, S_LO, S_HI, REG_LO, CONJ, S + 1>(v, bases);
     }
 }
@@ -154,42 +149,16 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
     }
 }
 
-#ifndef RC_B4_LB
-#define RC_B4_LB 16  // R = 64: input rows in flight per batch (8 pairs; 32 leave no room next to the register tail)
-#endif
-#ifndef RC_B4_PIPE
-#define RC_B4_PIPE 1  // R = 64, default window: input rows as a two-deep pipeline of RC_B4_PIPE_LB-row batches (-0.7 %; 8 rows: flat, 32 rows = all in flight: +1.5 %)
-#endif
-#ifndef RC_B4_PIPE_LB
-#define RC_B4_PIPE_LB 16
-#endif
-#ifndef RC_B4_TAILREG_MAX
-#define RC_B4_TAILREG_MAX 64  // largest R whose carried tail lives in registers (above: per-workgroup scratch)
-#endif
-#ifndef RC_B4_LGKM
-#define RC_B4_LGKM 1
-#endif
 // the exchange barriers order LDS traffic only: global stores of the epilogue (this thread's own output and tail
 // addresses) may still be in flight when the next hop starts
 #define BIG4_BAR()                                                                       \
     do {                                                                                 \
         if (RC_B4_ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
-        else if (RC_B4_LGKM) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
-        else __syncthreads();                                                            \
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");           \
     } while (0)
-#ifndef RC_B4_TAILNT
-#define RC_B4_TAILNT 0  // 1: non-temporal tail-scratch accesses (experiment)
-#endif
-__device__ __forceinline__ v2f tail_ld(GV2 p) { return RC_B4_TAILNT ? __builtin_nontemporal_load(p) : *p; }
-__device__ __forceinline__ void tail_st(GV2W p, v2f v) {
-    if (RC_B4_TAILNT) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
-#ifndef RC_B4_DMA
-#define RC_B4_DMA 0
-#endif
 #ifndef RC_B4_ABL
-#define RC_B4_ABL 0  // timing-only ablations of big4_kernel: 1 no input loads, 2 no tail scratch traffic, 4 no output stores
+#define RC_B4_ABL 0  // timing-only ablations (`make variant`; results are wrong by construction): 1 no input loads,
+                     // 4 no output stores, 8 the E2 / E3 barriers become fences, 16 no barrier at all
 #endif
 // (timing-only, RC_B4_ABL bit 8: the E2 / E3 barriers become compiler fences - what desynchronised waves would buy)
 #define BIG4_BAR_MID()                                                          \
@@ -197,44 +166,25 @@ __device__ __forceinline__ void tail_st(GV2W p, v2f v) {
         if (RC_B4_ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
         else BIG4_BAR();                                                        \
     } while (0)
-#ifndef RC_B4_EB
-#define RC_B4_EB 4
-#endif
-#ifndef RC_B4_TPRE
-#define RC_B4_TPRE 0
-#endif
-// R = 64: the last inverse stage (the one that pairs head sample q with tail sample q + PH) is computed inside
-// the epilogue, one register pair at a time with its twiddle rebuilt on the spot, instead of inside I3 with 16
-// twiddles (32 VGPRs) live next to the 128 data registers: that is what makes room for the carried tail
-#ifndef RC_B4_OVL
-#define RC_B4_OVL 5  // R = 64. bit 0: E1's second round of stores interleaved with F2 on the first group; bit 1: E2's
-                     // second round with F3 on the first round's sets; bit 2: E4's first round with I2 on the second
-                     // group and its second round with I3 on the first half; bit 3: E3's first round with I1 on the
-                     // second round's sets
-#endif
-#ifndef RC_B4_OVL_K
-#define RC_B4_OVL_K 4  // VALU instructions between two of the interleaved LDS stores (3 / 4 / 5 / 6 / 8 measured: flat, 4 best)
-#endif
-#ifndef RC_B4_PAIRLOAD
-#define RC_B4_PAIRLOAD 1  // input rows fetched in butterfly-pair order, stage 0 inside the load loop
-#endif
-#ifndef RC_B4_LOCALID
-#define RC_B4_LOCALID 1  // R = 64: thread identities re-derived per phase from an opaque copy of the thread id
-#endif
-#ifndef RC_B4_FUSE_LAST
-#define RC_B4_FUSE_LAST 1
-#endif
+// R = 64 (BASELINE C5): what the measurements of rounds 2-4 settled (docs/LAB_NOTES, DESIGN.md 5.4, profiles/r04a_c5_ablations.txt)
+//  * the last inverse stage (the one that pairs head sample q with tail sample q + PH) is computed inside the
+//    epilogue, one register pair at a time with its twiddle rebuilt on the spot, instead of inside I3 with 16
+//    twiddles (32 VGPRs) live next to the 128 data registers: that is what makes room for the carried tail
+//  * E1's second round of stores is interleaved with F2 on the first group, E4's first round with I2 on the second
+//    group and its second round with I3 on the first half: one ds_write per BIG4_OVL_K VALU instructions (3 / 4 / 5 / 6 /
+//    8 measured: flat, 4 best); the same for E2 / E3 measured within noise and is not built
+//  * input rows are fetched in butterfly-pair order (0, R/2, 1, R/2 + 1, ...) with stage 0 inside the load loop, as a
+//    two-deep pipeline of 16-row batches (8 rows: flat, 32 rows = everything in flight: +1.5 %)
+//  * thread identities are re-derived per phase from an opaque copy of the thread id (hoisted they are spilled)
+constexpr int BIG4_OVL_K = 4, BIG4_PIPE_ROWS = 16, BIG4_EPI_BATCH = 4, BIG4_TAIL_LDS = 5;
 constexpr int BIG4_T = 512;
 constexpr int BIG4_XBUF = 16400;  // exchange buffer, float2 slots (16384 + the 15 of the E1 / E3 index map)
 // tables behind the buffer: W_M^r [TA], W_N^r [TR] for r <= RES/2, thread 0's second twiddle base
-// R = 64 with the carried tail in registers: the last RC_B4_TAIL_LDS of a thread's 32 tail pairs live in LDS instead
+// R = 64 with the carried tail in registers: the last BIG4_TAIL_LDS of a thread's 32 tail pairs live in LDS instead
 // (behind the tables; 512 float2 per pair: what is left of the 160 KiB takes three) - 192 data registers plus the
 // temporaries of the widest phases are ~8 more than the allocator places, and what it spills instead goes through
 // scratch memory, in line behind the output stores (8 spilled dwords cost 2.3 %)
-#ifndef RC_B4_TAIL_LDS
-#define RC_B4_TAIL_LDS 5
-#endif
-constexpr int big4_tail_lds(int R) { return (R == 64 && R <= RC_B4_TAILREG_MAX) ? RC_B4_TAIL_LDS : 0; }
+constexpr int big4_tail_lds(int R) { return R == 64 ? BIG4_TAIL_LDS : 0; }
 // ... and to make room for them the W_N^r table (two reads per thread and hop, in the pair stage) stays in global
 // memory for that kernel: its loads are issued in front of the E2 exchange, far from any store
 constexpr bool big4_tr_global(int R) { return big4_tail_lds(R) > 3; }
@@ -250,12 +200,8 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
     constexpr bool TRG = big4_tr_global(R);
     constexpr int T_A = BIG4_XBUF, T_R = T_A + RES / 2 + 1, SCR = T_R + (TRG ? 0 : RES / 2 + 1);
     constexpr int TL = big4_tail_lds(R), TLB = SCR + 8, PHR = R / 2 - TL;  // tail pairs [PHR, R/2) live at lds[TLB + ...]
-    constexpr bool TAIL_GLOBAL = R > RC_B4_TAILREG_MAX;
-    constexpr bool OVL1 = (RC_B4_OVL & 1) && R == 64;
-    constexpr bool OVL2 = (RC_B4_OVL & 2) && R == 64 && R <= RC_B4_TAILREG_MAX;
-    constexpr bool OVL3 = (RC_B4_OVL & 8) && R == 64;
-    constexpr bool OVL4 = (RC_B4_OVL & 4) && R == 64 && RC_B4_FUSE_LAST && !RC_B4_DMA && R <= RC_B4_TAILREG_MAX;
-    constexpr bool LEAN = !TAIL_GLOBAL && R > 32;  // 192 data registers: everything else is kept short-lived
+    constexpr bool OVL = R == 64;   // exchange stores interleaved with the next pass (E1, E4)
+    constexpr bool LEAN = R > 32;   // 192 data registers: everything else is kept short-lived
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const uint32_t run = blockIdx.x % p.runs_per_channel;
@@ -267,13 +213,6 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
     GF xc = (GF)p.x + (size_t)ch * p.in_stride;
     GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
     GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
-    GV2W tsc = (GV2W)p.ybuf + (size_t)blockIdx.x * (H / 2);  // TAIL_GLOBAL: this workgroup's tail scratch
-    if constexpr (TAIL_GLOBAL) {  // uniform base in SGPRs + a 32-bit lane offset: no 64-bit address per access
-        const unsigned long long ta = (unsigned long long)tsc;
-        const unsigned tlo = __builtin_amdgcn_readfirstlane((unsigned)ta);
-        const unsigned thi = __builtin_amdgcn_readfirstlane((unsigned)(ta >> 32));
-        tsc = (GV2W)(((unsigned long long)thi << 32) | tlo);
-    }
     const unsigned lane2 = 2u * (unsigned)tid;
     const uint32_t pitch = PITCH1 ? 1u : p.pitch;
     const int wv = tid >> 6;
@@ -290,16 +229,11 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
         }
         __syncthreads();
     }
-    v2f tail[TAIL_GLOBAL ? 1 : PHR];
-    if constexpr (!TAIL_GLOBAL) {
+    v2f tail[PHR];
 #pragma unroll
-        for (int q = 0; q < PHR; ++q) tail[q] = v2f{0.f, 0.f};
+    for (int q = 0; q < PHR; ++q) tail[q] = v2f{0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < TL; ++q) lds[TLB + 512 * q + tid] = make_float2(0.f, 0.f);  // (read back by this thread only)
-    } else {
-#pragma unroll
-        for (int q = 0; q < PH; ++q) stg2(tsc + T * q + (unsigned)tid, make_float2(0.f, 0.f));
-    }
+    for (int q = 0; q < TL; ++q) lds[TLB + 512 * q + tid] = make_float2(0.f, 0.f);  // (read back by this thread only)
     const bool is0 = tid == 0;
     Stamps stp;
     stp.init();
@@ -307,14 +241,9 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
     // compiler hoists the ~40 loop-invariant LDS bases / residues out of the hop loop and then spills them
     auto ptid = [&]() {
         int t = tid;
-        if (RC_B4_LOCALID && R > 32) opaque(t);  // (R = 32 has the registers: there the hoisted values are 2 % faster)
+        if (R > 32) opaque(t);  // (R = 32 has the registers: there the hoisted values are 2 % faster)
         return t;
     };
-    // RC_B4_DMA (R = 32): the next hop's whole window (N floats = the exchange buffer's size) is fetched by LDS-DMA
-    // (global_load_lds_dwordx4: no VGPRs) into the exchange buffer while it is idle - from the last E4 read to the
-    // next E1 write - so that its latency runs under I3 and the epilogue instead of in front of F1
-    constexpr bool DMA = RC_B4_DMA && R == 32;
-    bool dma_ready = false;
     for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         int tt = tid;  // per-hop opaque copy for the scratch addresses (hoisted, they would be 2 PH live VGPRs)
@@ -331,25 +260,20 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 sbW = v2f{a0.y, a1.y};
             }
             const HannK64 &HW = R == 32 ? HANN_W15 : HANN_W16;
-            // every load of the hop in flight at once when the window is computed (one memory latency per
-            // hop); batches of 16 when the window comes from its table too (register budget)
-            constexpr int LB = HANN ? (R > 32 ? RC_B4_LB : R) : 16;
-            if (DMA && dma_ready) {  // every wave waits for its own DMAs, then all of them are visible to all.
-                // The PH output stores of the previous hop were issued behind the DMAs and may stay in flight
-                // (vector memory operations retire in order)
-                if (PITCH1 && k - 1 >= k_begin) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            }
+            // R = 32 with the computed window: every load of the hop in flight at once (one memory latency per hop);
+            // batches of 16 when the window comes from its table too (register budget); R = 64 with the computed
+            // window: the pipeline below
+            constexpr int LB = HANN ? R : 16;
             // rows are fetched in the order 0, R/2, 1, R/2 + 1, ...: butterfly stage 0 pairs row q with row q + R/2 (registers
             // brev(q) and brev(q) + 1), and the compiler folds the second row's window multiply into that butterfly, so a
             // row loaded long before its partner would wait for it as two live values (raw samples and window)
-#define ROW(i) (RC_B4_PAIRLOAD ? (((i) >> 1) + ((i) & 1) * (R / 2)) : (i))
-            if constexpr (RC_B4_PIPE && HANN && R == 64 && RC_B4_PAIRLOAD && !DMA) {
+#define ROW(i) (((i) >> 1) + ((i) & 1) * (R / 2))
+            if constexpr (HANN && R == 64) {
                 // Two batches of rows in flight: batch i + 2 is requested as soon as batch i has been folded into
                 // v[] (stage 0), so a hop exposes about one memory latency instead of one per batch. The window
                 // values are computed pair by pair inside the fold (hoisted over a whole batch they are LB more
                 // live pairs, and the allocator spills)
-                constexpr int PB = RC_B4_PIPE_LB, NB = R / PB;
+                constexpr int PB = BIG4_PIPE_ROWS, NB = R / PB;
                 float xp0[2][PB], xp1[2][PB];
                 auto issue = [&](int i, float (&x0)[PB], float (&x1)[PB]) {
 #pragma unroll
@@ -392,11 +316,6 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 float xr0[LB], xr1[LB], wr0[HANN ? 1 : LB], wr1[HANN ? 1 : LB];
 #pragma unroll
                 for (int q = 0; q < LB; ++q) {
-                    if (DMA && dma_ready) {  // (uniform) z[n], n = tid + 512 q, sits at float2 slot n
-                        const float2 zz = lds[tid + T * ROW(q0 + q)];
-                        xr0[q] = zz.x;
-                        xr1[q] = zz.y;
-                    } else
                     if (RC_B4_ABL & 1) {  // timing only: no input loads
                         xr0[q] = (float)(lane2 + ROW(q0 + q)) + (float)k;
                         xr1[q] = xr0[q] * 0.5f;
@@ -420,23 +339,18 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 }
                 // butterfly stage 0 right here (registers brev(q) and brev(q) + 1 = rows q and q + R/2): a +- b with
                 // a = x_q w_q and b = x_{q+R/2} w_{q+R/2} is one multiply and two FMAs
-                if constexpr (RC_B4_PAIRLOAD) {
 #pragma unroll
-                    for (int q = 0; q < LB; q += 2) {
-                        const v2f a = v2f{xr0[q], xr1[q]} * wq[q], xh = v2f{xr0[q + 1], xr1[q + 1]};
-                        v[brev_c(ROW(q0 + q), b)] = __builtin_elementwise_fma(xh, wq[q + 1], a);
-                        v[brev_c(ROW(q0 + q), b) + 1] = __builtin_elementwise_fma(-xh, wq[q + 1], a);
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < LB; ++q) v[brev_c(q0 + q, b)] = v2f{xr0[q], xr1[q]} * wq[q];
+                for (int q = 0; q < LB; q += 2) {
+                    const v2f a = v2f{xr0[q], xr1[q]} * wq[q], xh = v2f{xr0[q + 1], xr1[q + 1]};
+                    v[brev_c(ROW(q0 + q), b)] = __builtin_elementwise_fma(xh, wq[q + 1], a);
+                    v[brev_c(ROW(q0 + q), b) + 1] = __builtin_elementwise_fma(-xh, wq[q + 1], a);
                 }
                 // the register tail leaves no room for a second batch in flight: keep the batches apart
-                if constexpr (!TAIL_GLOBAL && R > 32) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (R > 32) __builtin_amdgcn_sched_barrier(0);
             }
 #undef ROW
             stp.mark(0);
-            dit_g<R, RC_B4_PAIRLOAD ? 1 : 0, b - 1, 0, false, false>(v);
+            dit_g<R, 1, b - 1, 0, false, false>(v);
         }
         stp.mark(1);
         // ---- E1: F1 -> F2, round g moves the registers with position bit 5 = g
@@ -446,7 +360,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             const int bs = (int)(__brev((unsigned)t_) >> 23);            // brev9(t)
             const int b1s = (bs << 5) + (bs >> 5);                       // e1(q | brev9(t) << 5) = q + this
             const int b1l = lf + (uu << 10) + uu;                        // e1(lf | j << 5 | uu << 10) = (j << 5) + this
-            if constexpr (OVL1) {
+            if constexpr (OVL) {
                 // R = 64, two rounds: the LDS takes the 32 stores of a wave at ~50 cycles apiece while all eight waves
                 // store (80 B/clk per CU), so the second round's stores are issued one at a time between the butterflies
                 // of F2 on the first round's group instead of in front of a barrier
@@ -472,7 +386,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // one DS write
-                    __builtin_amdgcn_sched_group_barrier(0x2, RC_B4_OVL_K, 0);  // then K VALU
+                    __builtin_amdgcn_sched_group_barrier(0x2, BIG4_OVL_K, 0);  // then K VALU
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 BIG4_BAR();
@@ -499,7 +413,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             }
             }
         }
-        if constexpr (!OVL1) {
+        if constexpr (!OVL) {
         stp.mark(2);
         {   // F2: stages b..b+4 on each group; base W_RES^(lf | g << 5) = W_M^(16 lf) * (g ? W_64 : 1)
             const int lf = ptid() & 31;
@@ -530,24 +444,10 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
             for (int rnd = 0; rnd < G; ++rnd) {
                 BIG4_BAR_MID();
-                if (OVL2 && rnd == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kk = 0; kk < 32; ++kk) {
                     if (R == 32) lds[b2s + (kk << 5)] = to_f2(w[kk]);
                     else lds[b2s + ((kk >> 4) << 5) + ((kk & 15) << 6)] = to_f2(w[32 * (kk >> 4) + 16 * rnd + (kk & 15)]);
-                }
-                if constexpr (OVL2) {
-                    if (rnd == 1) {  // F3 on the sets round 0 delivered (residues tid and tid + 512) between round 1's stores
-#pragma unroll
-                        for (int gp = 0; gp < NS / 2; ++gp)
-                            dit_g<16, b + 5, b + 8, b + 5, false, true, LEAN>(st[2 * gp], to_v(lds[T_A + tid + 512 * gp]));
-#pragma unroll
-                        for (int i = 0; i < 32; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, RC_B4_OVL_K, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
                 BIG4_BAR_MID();
 #pragma unroll
@@ -572,7 +472,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 const v2f k16 = {W32_RE[2], W32_IM[2]};
                 v2f wb = vcmul(v2f{wa.x, -wa.y}, k16);  // W_M^(RES - r) = W_16 conj(W_M^r)
                 if (gp == 0 && is0) wb = v2f{W32_RE[1], W32_IM[1]};  // thread 0: residue RES/2 -> W_32
-                if constexpr (!OVL2) dit_g<16, b + 5, b + 8, b + 5, false, true, LEAN>(va, wa);
+                dit_g<16, b + 5, b + 8, b + 5, false, true, LEAN>(va, wa);
                 dit_g<16, b + 5, b + 8, b + 5, false, true, LEAN>(vb, wb);
             }
             // thread 0, group 0: residues 0 and RES/2 pair with themselves (hop4_kernel's re-deal)
@@ -642,7 +542,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 pb[brev_c(q, 4)] = vb[q];
             }
             dit_g<16, 0, 3, 0, true, false>(pa);
-            if constexpr (!OVL3) dit_g<16, 0, 3, 0, true, false>(pb);  // (OVL3: between the stores of E3's first round)
+            dit_g<16, 0, 3, 0, true, false>(pb);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 va[q] = pa[q];
@@ -656,7 +556,6 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
             for (int rnd = 0; rnd < G; ++rnd) {
                 BIG4_BAR_MID();
-                if (OVL3 && rnd == 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     if (R == 64 && ((s & 1) != rnd)) continue;
@@ -668,18 +567,6 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                     const int base = n0 + ((n0 >> 10) & 15);
 #pragma unroll
                     for (int q = 0; q < 16; ++q) lds[base + q] = to_f2(st[s][q]);
-                }
-                if constexpr (OVL3) {
-                    if (rnd == 0) {  // I1 on the sets of round 1 (the vb of both pairs; they hold brev4-ordered inputs)
-#pragma unroll
-                        for (int gp = 0; gp < NS / 2; ++gp) dit_g<16, 0, 3, 0, true, false>(st[2 * gp + 1]);
-#pragma unroll
-                        for (int i = 0; i < 32; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x2, RC_B4_OVL_K, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
                 BIG4_BAR_MID();
 #pragma unroll
@@ -694,9 +581,9 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             }
         }
         stp.mark(6);
-        constexpr bool FUSE = R == 64 && RC_B4_FUSE_LAST;
+        constexpr bool FUSE = R == 64;  // the last inverse stage runs inside the epilogue
         v2f y[R];
-        if constexpr (OVL4) {
+        if constexpr (OVL) {
             // I2 on group 0; E4 round 0's stores between the butterflies of I2 on group 1; E4 round 1's stores between
             // those of I3 (stages 9..m-2) on the half that round 0 delivered
             const int tid = ptid(), l4 = tid & 15, hi = tid >> 4;
@@ -725,7 +612,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x2, RC_B4_OVL_K, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, BIG4_OVL_K, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             stp.mark(7);
@@ -748,7 +635,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x2, RC_B4_OVL_K, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, BIG4_OVL_K, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             BIG4_BAR();
@@ -793,49 +680,10 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             }
         }
         }
-        if constexpr (DMA) {
-            dma_ready = k + 1 < k_end;
-            if (dma_ready) {
-                BIG4_BAR();  // every wave has its E4 data: the buffer is free
-                typedef __attribute__((address_space(3))) void *LP;
-                typedef const __attribute__((address_space(1))) void *GP;
-                GF s2 = hop_src(p, xc, xt, k + 1);
-                float *ldsf = reinterpret_cast<float *>(lds);
-                const int lane = tid & 63;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {  // 16 KiB per wave: 16 pieces of 64 lanes x 16 bytes
-                    const int c = wv * 16 + j;
-                    __builtin_amdgcn_global_load_lds((GP)(s2 + c * 256 + lane * 4), (LP)(ldsf + c * 256), 16, 0, 0);
-                }
-            }
-        }
         stp.mark(8);
-        // R = 64: the carried tail comes back from the scratch; requested here, behind the last exchange, so that
-        // its latency hides under I3 (v is dead: there are registers for it)
-        constexpr bool TPRE = TAIL_GLOBAL && RC_B4_TPRE;
-        v2f tpre[TPRE ? PH : 1];
-        if constexpr (TPRE) {
-#pragma unroll
-            for (int q = 0; q < PH; ++q) tpre[q] = tail_ld((GV2)tsc + T * q + (unsigned)tt);
-        }
-        if constexpr (OVL4) {
-        } else if constexpr (FUSE) {  // stages 9..m-2 on each half (the two halves share their twiddles)
-            const v2f wfl = to_v(lds[T_A + ptid()]);
-            const v2f wf2 = vcsq(wfl);
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                v2f grp[R / 2];
-#pragma unroll
-                for (int j = 0; j < R / 2; ++j) grp[j] = y[(R / 2) * g + j];
-                dit_g<R / 2, 9, m - 2, 9, true, true, LEAN>(grp, wf2);
-#pragma unroll
-                for (int j = 0; j < R / 2; ++j) y[(R / 2) * g + j] = grp[j];
-            }
-        } else {
-            dit_g<R, 9, m - 1, 9, true, true>(y, to_v(lds[T_A + ptid()]));
-        }
+        if constexpr (!OVL) dit_g<R, 9, m - 1, 9, true, true>(y, to_v(lds[T_A + ptid()]));  // (R = 64: done above)
         stp.mark(9);
-        // ---- epilogue: synthesis window, overlap-add, store (tail in registers or in the scratch)
+        // ---- epilogue: synthesis window, overlap-add, store (the carried tail in registers, R = 64: its last pairs in LDS)
         {
             GF win = per_hop(p.window);
             GF esrc = per_hop(p.env);
@@ -863,27 +711,11 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             const int64_t g0 = k * (int64_t)H;
             GFW dst = outc + (g0 / (int64_t)pitch - p.out_origin);
             const uint32_t kr = (uint32_t)(g0 % pitch);
-            constexpr int EB = R > 32 ? RC_B4_EB : 8;  // batch of table / tail loads in flight (register budget)
-            constexpr bool TPIPE = TAIL_GLOBAL && !TPRE;  // tail loads one batch ahead of their use
-            v2f tnx[TPIPE ? EB : 1];
-            if constexpr (TPIPE) {
-#pragma unroll
-                for (int q = 0; q < EB; ++q)
-                    tnx[q] = (RC_B4_ABL & 2) ? v2f{0.f, 0.f} : tail_ld((GV2)tsc + T * q + (unsigned)tt);
-            }
+            constexpr int EB = R > 32 ? BIG4_EPI_BATCH : 8;  // batch of table loads / window values in flight (register budget)
 #pragma unroll
             for (int q0 = 0; q0 < PH; q0 += EB) {
                 float wr0[EB], wr1[EB], wt0[EB], wt1[EB], e0[EB], e1[EB];
                 v2f tq[EB];
-                if constexpr (TPIPE) {
-#pragma unroll
-                    for (int q = 0; q < EB; ++q) tq[q] = tnx[q];
-                    if (q0 + EB < PH) {
-#pragma unroll
-                        for (int q = 0; q < EB; ++q)
-                            tnx[q] = (RC_B4_ABL & 2) ? v2f{0.f, 0.f} : tail_ld((GV2)tsc + T * (q0 + EB + q) + (unsigned)tt);
-                    }
-                }
 #pragma unroll
                 for (int q = 0; q < EB; ++q) {
                     if constexpr (!HANN) {
@@ -902,9 +734,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                                        __builtin_elementwise_fma(v2f{HE.c[q0 + q], HE.c[q0 + q]}, cbE, hfE));
                         wr0[q] = wh.x, wr1[q] = wh.y, wt0[q] = wt.x, wt1[q] = wt.y, e0[q] = ev.x, e1[q] = ev.y;
                     }
-                    if constexpr (TPRE) tq[q] = tpre[q0 + q];
-                    else if constexpr (TAIL_GLOBAL) {}
-                    else if (q0 + q < PHR) tq[q] = tail[q0 + q];
+                    if (q0 + q < PHR) tq[q] = tail[q0 + q];
                     else tq[q] = to_v(lds[TLB + 512 * (q0 + q - PHR) + tt]);
                 }
 #pragma unroll
@@ -935,15 +765,11 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                             if (d1 * pitch == a1) dst[d1] = o.y;
                         }
                     }
-                    if constexpr (TAIL_GLOBAL) {
-                        if (!(RC_B4_ABL & 2)) tail_st(tsc + T * (q0 + q) + (unsigned)tt, nt);
-                        else if (nt.x == 1.2345f) stg2(tsc, to_f2(nt));  // (keeps nt alive)
-                    }
-                    else if (q0 + q < PHR) tail[q0 + q] = nt;
+                    if (q0 + q < PHR) tail[q0 + q] = nt;
                     else lds[TLB + 512 * (q0 + q - PHR) + tt] = to_f2(nt);
                 }
                 // (register tail at R = 64: 192 registers are taken; keep the batches' window / twiddle temporaries apart)
-                if constexpr (!TAIL_GLOBAL && R > 32) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (R > 32) __builtin_amdgcn_sched_barrier(0);
             }
         }
         stp.mark(10);
@@ -972,7 +798,8 @@ hipError_t launch_big4_r(const HopParams &p, hipStream_t s) {
 
 size_t big4_tail_scratch_floats(int log2n) {
     const int R = log2n == 16 ? 64 : 32;
-    return R > RC_B4_TAILREG_MAX ? ((size_t)1 << log2n) / 2 : 0;
+    (void)R;
+    return 0;  // (round 2's R = 64 kernel carried the tail through a per-workgroup scratch; since round 3 it lives in registers / LDS)
 }
 hipError_t launch_big4(int log2n, const HopParams &p, hipStream_t s) {
     if (log2n == 15) return launch_big4_r<32>(p, s);

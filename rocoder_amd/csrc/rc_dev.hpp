@@ -47,9 +47,6 @@ constexpr int clog2(int v) { return v <= 1 ? 0 : 1 + clog2(v >> 1); }
 // 16 -> 512 threads, 4 waves/SIMD, 4 passes)
 // Timing-only diagnostic builds (results are wrong): bit 0 = no phase hash/sincos, bit 1 = no global
 // loads/stores, bit 2 = no LDS exchanges/barriers, bit 3 = no butterflies, bit 4 = no middle stage.
-#ifndef RC_ABLATE
-#define RC_ABLATE 0
-#endif
 #ifndef RC_LOADCH
 #define RC_LOADCH 32
 #endif
@@ -116,13 +113,11 @@ constexpr int lds_reg_off(int q) { return pad_idx(pos_of<B, LO>(0, q)); }
 
 template <class G, int LO>
 __device__ __forceinline__ void lds_store(const float2 (&v)[G::P], float2 *lds, int base) {
-    if (RC_ABLATE & 4) return;
 #pragma unroll
     for (int q = 0; q < G::P; ++q) lds[base + lds_reg_off<G::B, LO>(q)] = v[q];
 }
 template <class G, int LO>
 __device__ __forceinline__ void lds_load(float2 (&v)[G::P], const float2 *lds, int base) {
-    if (RC_ABLATE & 4) return;
 #pragma unroll
     for (int q = 0; q < G::P; ++q) v[q] = lds[base + lds_reg_off<G::B, LO>(q)];
 }
@@ -213,13 +208,6 @@ __device__ __forceinline__ float phase_rev_upper(uint32_t h) {
 // counter x = c * mul + k0 of c < M: (-cos, -sin) of bin c (lo*) and of bin c + M (up*)
 __device__ __forceinline__ void phase_ncs2_x(uint32_t x, float &lo_nc, float &lo_ns, float &up_nc,
                                              float &up_ns) {
-    if (RC_ABLATE & 1) {
-        lo_nc = __uint_as_float(0x3F000000u | (x & 0xFFFFu));
-        lo_ns = lo_nc + 1.0f;
-        up_nc = lo_nc + 2.0f;
-        up_ns = lo_nc + 3.0f;
-        return;
-    }
     const uint32_t h = phase_hash_x(x);
     const float fl = phase_rev_lower(h), fu = phase_rev_upper(h);
     lo_nc = __builtin_amdgcn_cosf(fl);

@@ -87,7 +87,6 @@ __device__ __forceinline__ void vdit_i(v2f a, v2f b, v2f &r, v2f &o) {
 }
 template <int NREG, int M_LOG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L>
 __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f}) {
-    if (RC_ABLATE & 8) return;
     const v2f sgn = CONJ ? v2f{1.0f, -1.0f} : v2f{-1.0f, 1.0f};
     v2f bases[S_HI - S_LO + 1];
     if (HAS_L) {

@@ -22,9 +22,6 @@ namespace {
 //     f3(n) = n + (n >> 5) + (n >> 8) keeps every access pattern at most 2-way conflicted on a few
 //     lanes; it is additive over disjoint bit fields, so each access is a per-thread base VGPR +
 //     an immediate offset.
-#ifndef RC_NTSTORE
-#define RC_NTSTORE 1  // non-temporal output stores (the window overlap of consecutive hops stays in the XCD's L2)
-#endif
 constexpr int f1_idx(int n) { return n + (n >> 5); }
 constexpr int HOP2_XBUF = 8192 + 256 + 32;
 constexpr int HOP2_LDS_FLOAT2 = HOP2_XBUF + 8 + 32 + 256 + 256 + 16 + 24 + 1024;  // 79 232 B
@@ -34,12 +31,8 @@ constexpr int HOP2_LDS_FLOAT2 = HOP2_XBUF + 8 + 32 + 256 + 256 + 16 + 24 + 1024;
 // 32-lane groups on 64 banks) so that the stores of all four exchanges are conflict-free (the old map
 // n + (n >> 5) + (n >> 8) was built for the read groups only and 2-way conflicted on the stores of
 // exchanges 1 and 3: SQ_LDS_DATA_FIFO_FULL for half of the SQ cycles).
-#ifndef RC_WMAP
-#define RC_WMAP 1
-#endif
 constexpr int F3_W[13] = {1, 2, 4, 8, 16, 32, 64, 131, 259, 520, 1038, 2079, 4156};
 constexpr int f3_idx(int n) {
-    if (!RC_WMAP) return n + (n >> 5) + (n >> 8);
     int r = 0;
     for (int i = 0; i < 13; ++i) r += ((n >> i) & 1) * F3_W[i];
     return r;
@@ -247,41 +240,32 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         }
         // ---- forward: F1 (done), E1, F2 (bits 5..8), E2, F3 (bits 9..12)
 #pragma unroll
-        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 128))) lds[bE1s + f3_idx(q)] = to_f2(vn[q]);
-        if (RC_ABLATE & 4) {
-#pragma unroll
-            for (int q = 0; q < P; ++q) v[q] = vn[q];
-        }
+        for (int q = 0; q < P; ++q) lds[bE1s + f3_idx(q)] = to_f2(vn[q]);
         if constexpr (SWP2) {
             if (k > k_first) epilogue(k - 1, vo);
         }
         st.mark(2);
-        if (!(RC_ABLATE & 32)) __syncthreads();
+        __syncthreads();
         st.mark(3);
 #pragma unroll
-        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 256))) v[q] = xld(lds, b4f3 + f3_idx(q << 4));
+        for (int q = 0; q < P; ++q) v[q] = xld(lds, b4f3 + f3_idx(q << 4));
         dit_stages<32, m, 5, 8, 4, false, true>(v, to_v(lds[T_B + l4]));
         st.mark(4);
         // E2 store is IN PLACE (same layout, same index map as the E1 load): each thread overwrites
         // exactly the elements it read, so no barrier is needed between the two
 #pragma unroll
-        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 128))) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);
+        for (int q = 0; q < P; ++q) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);
         st.mark(5);
-        if (!(RC_ABLATE & 32)) __syncthreads();
+        __syncthreads();
         st.mark(6);
         v2f va[16], vb[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            if (!(RC_ABLATE & (4 | 256))) {
-                va[q] = xld(lds, bAr + f3_idx((RES * q)));
-                vb[q] = xld(lds, bBr + f3_idx((RES * q)));
-            } else {
-                va[q] = v[q];
-                vb[q] = v[q + 16];
-            }
+            va[q] = xld(lds, bAr + f3_idx((RES * q)));
+            vb[q] = xld(lds, bBr + f3_idx((RES * q)));
         }
         st.mark(7);
-        if (!(RC_ABLATE & 32)) __syncthreads();
+        __syncthreads();
         st.mark(8);
         {
             const v2f wa = to_v(lds[T_A + tid]);  // W_8192^r
@@ -309,7 +293,6 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
             const uint32_t dx = (uint32_t)RES * key.mul;          // + 512 bins
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                if (RC_ABLATE & 16) continue;
                 // exp(-2 pi i (r + 512 q) / N) = wr * W32^q
 #if RC_PAIR_PK
                 const v2f wrv = to_v(wr);
@@ -330,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
             }
         }
         st.mark(10);
-        if (tid < 64 && !(RC_ABLATE & 64)) {  // wave 0: lanes 0..16 compute thread 0's 17 pairs from the scratch
+        if (tid < 64) {  // wave 0: lanes 0..16 compute thread 0's 17 pairs from the scratch
             const int i = tid;
             if (i <= 16) {
                 int ja, ia, ib;
@@ -367,26 +350,26 @@ __global__ __launch_bounds__(256, 2) void hop2_kernel(const HopParams p) {
         st.mark(12);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            if (!(RC_ABLATE & (4 | 128))) lds[bE3a + f3_idx(q)] = to_f2(pa[q]);
-            if (!(RC_ABLATE & (4 | 128))) lds[bE3b + f3_idx(q)] = to_f2(pb[q]);
+            lds[bE3a + f3_idx(q)] = to_f2(pa[q]);
+            lds[bE3b + f3_idx(q)] = to_f2(pb[q]);
         }
         st.mark(13);
         if constexpr (SWP) win_f1(vn);  // next hop's window + F1 while the E3 stores drain
-        if (!(RC_ABLATE & 32)) __syncthreads();
+        __syncthreads();
         st.mark(14);
 #pragma unroll
-        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 256))) v[q] = xld(lds, b4f3 + f3_idx(q << 4));
+        for (int q = 0; q < P; ++q) v[q] = xld(lds, b4f3 + f3_idx(q << 4));
         dit_stages<32, m, 4, 8, 4, true, true>(v, to_v(lds[T_B + l4]));
         st.mark(15);
 #pragma unroll
-        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 128))) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);  // in place (see E2)
+        for (int q = 0; q < P; ++q) lds[b4f3 + f3_idx(q << 4)] = to_f2(v[q]);  // in place (see E2)
         st.mark(16);
-        if (!(RC_ABLATE & 32)) __syncthreads();
+        __syncthreads();
         st.mark(17);
 #pragma unroll
-        for (int q = 0; q < P; ++q) if (!(RC_ABLATE & (4 | 256))) v[q] = xld(lds, bE4l + f3_idx((q << 8)));
+        for (int q = 0; q < P; ++q) v[q] = xld(lds, bE4l + f3_idx((q << 8)));
         st.mark(18);
-        if (!(RC_ABLATE & 32)) __syncthreads();
+        __syncthreads();
         st.mark(19);
         dit_stages<32, m, 9, 12, 8, true, true>(v, to_v(lds[T_A + tid]));
         st.mark(20);
@@ -440,22 +423,10 @@ __device__ __forceinline__ void wave_fence() {
 
 // Workgroup barrier of the hop loop. __syncthreads() also waits for vmcnt(0), i.e. for the previous hop's
 // output stores to be acknowledged; the exchanges only need this wave's LDS operations to have completed.
-#ifndef RC_LGKM_BARRIER
-#define RC_LGKM_BARRIER 1
-#endif
-// number of output pairs of a hop (of 16) whose store is deferred into the next hop's first pass; 0 = none
-#ifndef RC_DEFER_STORE
-#define RC_DEFER_STORE 0
-#endif
 #define HOP4_PAIR pair_regs_pk4
-#ifndef RC_XCD_RUNS
-#define RC_XCD_RUNS 1
-#endif
 #define HOP4_BAR()                                                                    \
     do {                                                                              \
-        if (RC_ABLATE & 32) break;                                                    \
-        if (RC_LGKM_BARRIER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-        else __syncthreads();                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
     } while (0)
 // RC_DK_BAND fused into the pair stage: |gain| of real-spectrum bin f <= N/2 (lo <= f <= hi: inside)
 __device__ __forceinline__ float band_gain(const HopParams &p, uint32_t f) {
@@ -487,7 +458,7 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
         if (tid == 0) {
             const uint32_t total = p.runs_per_channel * p.n_channels;
             unsigned got = 0xFFFFFFFFu;
-            if (RC_XCD_RUNS) {
+            {
                 const uint32_t G = (total + 7u) / 8u;
                 unsigned xcc;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -501,8 +472,6 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
                         break;
                     }
                 }
-            } else {
-                got = atomicAdd(p.run_counter, 1u);
             }
             *slot = got;
         }
@@ -593,34 +562,13 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);  // (the builtin returns int:
             const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));  // widen as unsigned)
             GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
-            if (RC_ABLATE & 4096) dst = outc + ((g0 - p.out_origin) & 0x3FFFF);  // timing only: 1 MiB target
-            if (RC_ABLATE & 2048) {  // timing only: the same bytes as 8 x 16-byte stores (wrong places)
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                v2f oo[PH];
-#pragma unroll
-                for (int q = 0; q < PH; ++q) {
-                    const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
-                                   __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
-                    oo[q] = (head[q] + tail[q]) * er;
-                }
-#pragma unroll
-                for (int q = 0; q < PH; q += 2) {
-                    const v4f o4 = {oo[q].x, oo[q].y, oo[q + 1].x, oo[q + 1].y};
-                    __builtin_nontemporal_store(o4, (v4f RC_AS1 *)(dst + 4 * T * (q / 2) + 2 * lane2));
-                }
-                return;
-            }
 #pragma unroll
             for (int q = 0; q < PH; ++q) {
                 const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
                                __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
                 const v2f o = (head[q] + tail[q]) * er;  // (y + tail) * (env * amp), stretcher.rs:97-100
-                if ((RC_ABLATE & 1024) && o.x != 1.2345e-30f) continue;
-#if RC_NTSTORE
+                // non-temporal: the output is written once; the window overlap of consecutive hops stays in the XCD's L2
                 __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));
-#else
-                *(GV2W)(dst + 2 * T * q + lane2) = o;
-#endif
             }
         } else {
             const int64_t kq = g0 / pitch;
@@ -667,10 +615,8 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
                                __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
                 const v2f o = (head[q] + tail[q]) * er;
                 const float ox = o.x, oy = o.y;
-                if (!(RC_ABLATE & 1024) || ox == 1.2345e-30f) {  // (bit 1024, timing only: no output stores)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ox), rsrc, r == 0 ? d4 : DROP, 0, 0);  // a0 = d * pitch
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(oy), rsrc, r + 1 == pitch ? d4 + 4u : DROP, 0, 0);
-                }
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ox), rsrc, r == 0 ? d4 : DROP, 0, 0);  // a0 = d * pitch
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(oy), rsrc, r + 1 == pitch ? d4 + 4u : DROP, 0, 0);
                 d4 += qs4;
                 r += rs;
                 if (r >= pitch) {
@@ -681,28 +627,9 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             // (one store per row - the two samples are never both kept - was measured too: 4.64-4.76 against 4.66-4.69 ms)
         }
     };
-    // Deferred output stores (pitch 1). A CU drains about 11 bytes per clock towards memory: the 8 KiB a wave
-    // writes per hop take ~750 cycles, and the four waves of a workgroup reach their epilogues together, so 16
-    // back-to-back stores stall a wave for ~2 500 cycles at issue (timing-only builds without the stores run
-    // 9 % faster, with 16-byte stores or an L2-resident target no faster). The epilogue therefore only
-    // computes the 16 output pairs; they are stored one or two at a time between the butterflies of the NEXT
-    // hop's first pass, behind that hop's input loads in issue order (loads no longer queue behind stores).
-    constexpr int DN = RC_DEFER_STORE;  // output pairs [PH - DN, PH) of a hop are stored during the next hop
-    constexpr bool DEFER = PITCH1 && DN > 0;
-    constexpr int D0 = PH - (DN > 0 ? DN : PH);
-    v2f od[DN > 0 ? DN : 1];
-    bool pend = false;
-    int64_t pend_k = 0;
-    auto emit = [&](int q0, int q1) {
-        if (!DEFER || !pend) return;
-        const unsigned long long da = (unsigned long long)(outc + (pend_k * (int64_t)H - p.out_origin));
-        const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);
-        const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
-        GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
-#pragma unroll
-        for (int q = q0; q < q1; ++q)
-            if (q >= D0) __builtin_nontemporal_store(od[q - D0], (GV2W)(dst + 2 * T * q + lane2));
-    };
+    // (Output stores: a CU drains about 11 bytes per clock towards memory, so the 16 back-to-back stores of a hop
+    // stall a wave at issue - timing-only builds without them ran 9 % faster. Deferring them into the next hop's
+    // first pass was built in round 2 and measured worse at every depth (the registers it needs spill): not here.)
     for (int64_t k = ((k_begin > 0 && !stash_first) ? k_begin - 1 : k_begin); k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         v2f v[P];
@@ -712,11 +639,6 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             float xr0[P], xr1[P];
 #pragma unroll
             for (int q = 0; q < P; ++q) {
-                if (RC_ABLATE & 512) {
-                    xr0[q] = (float)(lane2 + q) + (float)k;
-                    xr1[q] = xr0[q] * 0.5f;
-                    continue;
-                }
                 xr0[q] = (src + 2 * T * q)[lane2];
                 xr1[q] = (src + 2 * T * q)[lane2 + 1];
             }
@@ -732,22 +654,9 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
                 const v2f a = v2f{xr0[q], xr1[q]} * wl, xh = v2f{xr0[q + 16], xr1[q + 16]};
                 v[2 * brev_c(q, 4)] = __builtin_elementwise_fma(xh, wh, a);
                 v[2 * brev_c(q, 4) + 1] = __builtin_elementwise_fma(-xh, wh, a);
-                if (q & 1) emit(q / 2, q / 2 + 1);
             }
             st.mark(0);
-            if (DEFER) {
-                dit_stages<32, m, 1, 1, 0, false, false>(v);
-                emit(8, 10);
-                dit_stages<32, m, 2, 2, 0, false, false>(v);
-                emit(10, 12);
-                dit_stages<32, m, 3, 3, 0, false, false>(v);
-                emit(12, 14);
-                dit_stages<32, m, 4, 4, 0, false, false>(v);
-                emit(14, 16);
-                pend = false;
-            } else {
-                dit_stages<32, m, 1, 4, 0, false, false>(v);
-            }
+            dit_stages<32, m, 1, 4, 0, false, false>(v);
             st.mark(1);
         }
         // ---- E1 (cross-wave), round A: position bit 4 clear. Own region (last read by this wave in
@@ -1004,24 +913,6 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
                 __syncthreads();
                 if (tid == 0 && !(p.diag_flags & RC_DIAG_SKIP_SEAM_PUBLISH))
                     __hip_atomic_store(p.seam_flag + gr, p.seam_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else if (DEFER) {
-                const v2f amp2 = {p.amp, p.amp};
-                const v2f cbE = to_v(lds[T_H + 2 * T + 2 * tid]) * amp2, sbE = to_v(lds[T_H + 2 * T + 2 * tid + 1]) * amp2;
-                const v2f halfa = half2 * amp2;
-                const unsigned long long da = (unsigned long long)(outc + (k * (int64_t)H - p.out_origin));
-                const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);
-                const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));
-                GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
-#pragma unroll
-                for (int q = 0; q < PH; ++q) {
-                    const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
-                                   __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
-                    const v2f o = (y[q] + tail[q]) * er;  // (y + tail) * (env * amp), stretcher.rs:97-100
-                    if (q < D0) __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));
-                    else od[q - D0] = o;
-                }
-                pend = true;
-                pend_k = k;
             } else {
                 store_head(k, y);
             }
@@ -1030,7 +921,6 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
         for (int q = 0; q < PH; ++q) tail[q] = y[q + PH];
         st.mark(25);
     }
-    emit(0, PH);  // the last hop's outputs
 #if RC_STAMP
     if ((tid & 63) == 0 && p.spec) {
         unsigned *dbg = (unsigned *)p.spec + ((size_t)blockIdx.x * (T / 64) + (tid >> 6)) * 32;

@@ -226,9 +226,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
             load_hop<LOG2N>(v, p, xc, xt, per_hop(p.window), k, lane2);
             forward_passes<G, G::m, 0, true>(v, lds, ctx, wtab, st);
             lds_store<G, LL>(v, lds, ctx.lb[LL]);
-            if (!(RC_ABLATE & 4)) __syncthreads();
+            __syncthreads();
             middle_stage<LOG2N, MODE_FORWARD>(lds, tid, PhaseKey{0u, 1u}, rtab, spec);
-            if (!(RC_ABLATE & 4)) __syncthreads();
+            __syncthreads();
         }
     } else if constexpr (MODE == MODE_RESYNTH) {
         for (int64_t k = k_begin; k < k_end; ++k) {
@@ -236,9 +236,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
             GV2W spec = (GV2W)p.spec + hop_idx * N;
             const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
             middle_stage<LOG2N, MODE_RESYNTH>(lds, tid, key, rtab, spec);
-            if (!(RC_ABLATE & 4)) __syncthreads();
+            __syncthreads();
             lds_load<G, LL>(v, lds, ctx.lb[LL]);
-            if (!(RC_ABLATE & 4)) __syncthreads();
+            __syncthreads();
             inverse_passes<G, G::m>(v, lds, ctx, wtab, st);
             GFW y = (GFW)p.ybuf + hop_idx * N;
             GF wsrc = per_hop(p.window);
@@ -295,14 +295,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
             st.mark(0);
             forward_passes<G, G::m, 0, true>(v, lds, ctx, wtab, st);
             lds_store<G, LL>(v, lds, ctx.lb[LL]);
-            if (!(RC_ABLATE & 4)) __syncthreads();
+            __syncthreads();
             st.mark(12);
-            if (!(RC_ABLATE & 16)) middle_fused<LOG2N>(lds, tid, key, rtab);
+            middle_fused<LOG2N>(lds, tid, key, rtab);
             st.mark(13);
-            if (!(RC_ABLATE & 4)) __syncthreads();
+            __syncthreads();
             st.mark(14);
             lds_load<G, LL>(v, lds, ctx.lb[LL]);
-            if (!(RC_ABLATE & 4)) __syncthreads();
+            __syncthreads();
             st.mark(15);
             inverse_passes<G, G::m>(v, lds, ctx, wtab, st);
             if constexpr (HANN) {
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
                 __builtin_amdgcn_sched_barrier(0);
             }
             st.mark(27);
-            if ((RC_ABLATE & 2) ? (v[0].x == 1.2345f) : (k >= k_begin)) {
+            if (k >= k_begin) {
                 const int64_t g0 = k * (int64_t)H;  // absolute O index of this hop's first sample
                 GF esrc = per_hop(p.env);
                 if constexpr (PITCH1) {

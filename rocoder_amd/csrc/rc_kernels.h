@@ -141,7 +141,7 @@ struct BigOlaParams {
 };
 
 // kernel generation (rc_kernel_id): bump whenever a change to the kernels can move a measurement
-#define RC_KERNEL_ID "hop4+big4/r03b"
+#define RC_KERNEL_ID "hop4+big4/r04a"
 
 enum HopMode { MODE_FUSED = 0, MODE_FORWARD = 1, MODE_RESYNTH = 2 };
 // values a kernel may leave in *HopParams::err_word

@@ -70,7 +70,6 @@ __device__ __forceinline__ void run_pass(float2 (&v)[G::P], int tid,
         const int s = INV ? (S_LO + si) : (S_HI - si);
         const int r = s - LOR;
         const int half = 1 << r;
-        if (RC_ABLATE & 8) continue;
         float2 base = make_float2(1.f, 0.f);
         if (LOR > 0) base = bases[s - S_LO];
 #pragma unroll
@@ -171,10 +170,10 @@ __device__ __forceinline__ void forward_passes(float2 (&v)[G::P], float2 *lds,
         constexpr int LOR = lor_of<G>(PREV);
         if constexpr (!FIRST) {
             lds_store<G, PREV_LOR>(v, lds, c.lb[PREV_LOR]);
-            if (!(RC_ABLATE & 4)) __syncthreads();
+            __syncthreads();
             st.mark(SID);
             lds_load<G, LOR>(v, lds, c.lb[LOR]);
-            if (!(RC_ABLATE & 4)) __syncthreads();
+            __syncthreads();
             st.mark(SID + 1);
         }
         run_pass<G, LOR, lo, PREV - 1, false>(v, c.tid, wtab);
@@ -195,10 +194,10 @@ __device__ __forceinline__ void inverse_passes(float2 (&v)[G::P], float2 *lds,
             inverse_passes<G, lo, SID + 3>(v, lds, c, wtab, st);
             constexpr int LOR_DEEPER = lor_of<G>(lo);
             lds_store<G, LOR_DEEPER>(v, lds, c.lb[LOR_DEEPER]);
-            if (!(RC_ABLATE & 4)) __syncthreads();
+            __syncthreads();
             st.mark(SID);
             lds_load<G, LOR>(v, lds, c.lb[LOR]);
-            if (!(RC_ABLATE & 4)) __syncthreads();
+            __syncthreads();
             st.mark(SID + 1);
         }
         run_pass<G, LOR, lo, PREV - 1, true>(v, c.tid, wtab);
@@ -215,11 +214,6 @@ template <int LOG2N>
 __device__ __forceinline__ void load_hop(float2 (&v)[Geo<LOG2N>::P], const HopParams &p,
                                          GF xc, GF xt, GF win, int64_t k, unsigned lane2) {
     using G = Geo<LOG2N>;
-    if (RC_ABLATE & 2) {
-#pragma unroll
-        for (int q = 0; q < G::P; ++q) v[q] = make_float2((float)(lane2 + q), (float)(k + q));
-        return;
-    }
     // uniform source pointer: force it into SGPRs (the select may otherwise be done in VALU)
     const int64_t off = (k >= p.tail_hop_first) ? (k * (int64_t)p.step - p.tail_origin)
                                                 : (k * (int64_t)p.step - p.in_origin);
