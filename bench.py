@@ -53,7 +53,9 @@ LDS_READ_PEAK_GBS = 150e3    # MI355X_MICROARCH.md §LDS: ds_read_b64/b128, ever
 LDS_WRITE_PEAK_GBS = 45e3    # same: 38-51 TB/s for ds_write_b32..b128
 # rc_calib_valu on the reference box of profiles/README.md's normalised table (ns per packed-FMA wave instruction per
 # SIMD, eight waves per SIMD): kernel_ms_normalised = kernel_ms * REF / this box's value
-BOX_CALIB_REF_NS = 1.70
+BOX_CALIB_REF_NS = 1.74
+# reference shader clock for kernel_ms_at_ref_clock (MHz): what a typical box of the pool holds under the hop kernel
+SCLK_REF_MHZ = 2100.0
 
 
 def synth_on_device(torch, device, channels, length):
@@ -243,6 +245,22 @@ def main():
     note(f"plan {[(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan]}")
     barrier()
     note("first barrier passed")
+    # shader clock under THIS load, sampled by a host thread while the pre-heat and the timed steps run (boxes of the
+    # pool hold 2.0 - 2.15 GHz under the hop kernel; the calibration kernel below alone does not show it)
+    import threading
+
+    clk_samples, clk_stop = [], threading.Event()
+
+    def clk_sampler():
+        while not clk_stop.is_set():
+            try:
+                clk_samples.append((time.perf_counter(), float(torch.cuda.clock_rate(dev_index))))
+            except Exception:  # noqa: BLE001  (no SMI library on the box: the field stays null)
+                return
+            time.sleep(0.05)
+
+    clk_thread = threading.Thread(target=clk_sampler, daemon=True)
+    clk_thread.start()
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
             step()
@@ -274,6 +292,11 @@ def main():
         kernel_ms_median = statistics.median(per_call)
         kernel_ms_mean = sum(per_call) / len(per_call)
     note(f"timed region done: {dt:.4f} s")
+    clk_stop.set()
+    clk_thread.join(timeout=2.0)
+    t_end = t0 + dt
+    clk_under_load = [c for (tt, c) in clk_samples if t_end - 1.0 <= tt <= t_end]
+    sclk_mhz = statistics.median(clk_under_load) if clk_under_load else None
     dt = max_over_ranks(dt)
 
     # ---- box calibration: a fixed pure-VALU kernel on the same stream right after the timed
@@ -427,6 +450,14 @@ def main():
             roof["frac_normalised"] = round(achieved / HBM_PEAK_GBS * calib["ns_per_inst"] / BOX_CALIB_REF_NS, 4)
         elif calib:
             roof["box_calib_error"] = calib.get("error")
+        # the shader clock this box held under the load of the hop kernel (median of the SMI samples of the last second
+        # of pre-heat + timed steps) and the kernel time scaled to the reference clock
+        roof["sclk_mhz_under_load"] = sclk_mhz
+        roof["sclk_samples"] = len(clk_under_load)
+        if sclk_mhz:
+            roof["sclk_ref_mhz"] = SCLK_REF_MHZ
+            roof["kernel_ms_at_ref_clock"] = round(kernel_ms_median * sclk_mhz / SCLK_REF_MHZ, 4)
+            roof["frac_at_ref_clock"] = round(achieved / HBM_PEAK_GBS * SCLK_REF_MHZ / sclk_mhz, 4)
         if "copy_GBs" in extras:
             roof["measured_copy_GBs"] = round(extras["copy_GBs"], 1)
             roof["frac_measured_peak"] = round(achieved / extras["copy_GBs"], 4)
@@ -477,7 +508,6 @@ def main():
                 res["config"]["x_cpu_all_cores"] = round(value / many["value"], 1)
     # ---- the one collective of the path, AFTER the main line is complete and under a watchdog: a concat that hangs
     # (it is the only code here that a one-GPU box cannot rehearse) must not cost the measurement
-    import threading
 
     lock = threading.Lock()
     emitted = [False]

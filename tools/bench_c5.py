@@ -11,6 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rocoder_amd  # noqa: E402
+from boxclock import ClockSampler  # noqa: E402
 
 dev = torch.device("cuda", 0)
 res = {"diag": os.environ.get("ROCODER_DIAG", "0")}
@@ -26,16 +27,17 @@ with torch.cuda.stream(stream):
             for _ in range(4):
                 e.stretch_tensor(x8, out=out)
             stream.synchronize()
-        for _ in range(10):
-            e.stretch_tensor(x8, out=out)
-        stream.synchronize()
+        with ClockSampler(0) as clk:
+            for _ in range(40):
+                e.stretch_tensor(x8, out=out)
+            stream.synchronize()
         ms = e.kernel_times(10)
         _, hops, launches = e.last_kernel_stats()
         med = statistics.median(ms)
         res[f"N{N}"] = dict(ms_median=round(med, 3), ms_min=round(min(ms), 3), hops=hops, launches=launches,
                             hops_per_s=round(hops / med * 1e3), out_gsamples_s=round(out.numel() / med / 1e6, 1),
                             algo_read_GBs=round(hops * 4.0 * N / med / 1e6, 1),
-                            frac_hbm=round(hops * 4.0 * N / med / 1e6 / 8000.0, 4))
+                            frac_hbm=round(hops * 4.0 * N / med / 1e6 / 8000.0, 4), sclk_mhz_under_load=clk.median_mhz())
         e.close()
         del out
 print(json.dumps(res))

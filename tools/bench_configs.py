@@ -18,6 +18,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rocoder_amd  # noqa: E402
 from rocoder_amd import _lib  # noqa: E402
+from boxclock import ClockSampler  # noqa: E402
 
 
 def device_job(x, n=10, heat_s=1.0, **kw):
@@ -29,14 +30,15 @@ def device_job(x, n=10, heat_s=1.0, **kw):
         for _ in range(4):
             e.stretch_tensor(x, out=out)
         torch.cuda.current_stream().synchronize()
-    for _ in range(n):
-        e.stretch_tensor(x, out=out)
-    torch.cuda.current_stream().synchronize()
+    with ClockSampler(x.device.index or 0) as clk:
+        for _ in range(max(n, int(0.3 / max(1e-4, 1e-3 * statistics.median(e.kernel_times(4)))))):
+            e.stretch_tensor(x, out=out)
+        torch.cuda.current_stream().synchronize()
     ms = statistics.median(e.kernel_times(n))
     _, hops, launches = e.last_kernel_stats()
     N = kw["window_len"]
     r = dict(kernel_ms=round(ms, 3), hops=hops, launches=launches, out_msamples_s=round(out.numel() / ms / 1e3, 1),
-             frac_hbm_read_roofline=round(hops * 4.0 * N / ms / 1e6 / 8000.0, 4))
+             frac_hbm_read_roofline=round(hops * 4.0 * N / ms / 1e6 / 8000.0, 4), sclk_mhz_under_load=clk.median_mhz())
     e.close()
     return r
 

@@ -10,11 +10,14 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rocoder_amd  # noqa: E402
+from boxclock import ClockSampler  # noqa: E402
 
 dev = torch.device("cuda", 0)
 x = (torch.rand((2, 13_230_000), device=dev) - 0.5)
 res = {}
 stream = torch.cuda.Stream(dev)
+clk = ClockSampler(0)
+clk.__enter__()
 with torch.cuda.stream(stream):
     # "t" rows: a caller-supplied window (hanning ** 1.5: not the default, so the table-window kernels run -
     # hop2_kernel at 16384, the generic hop_kernel below)
@@ -47,4 +50,6 @@ with torch.cuda.stream(stream):
                             frac_hbm_read=round(hops * 4.0 * N / ms / 1e6 / 8000.0, 4))
         e.close()
         del out
+clk.__exit__()
+res["sclk_mhz_under_load"] = clk.median_mhz()
 print(json.dumps(res, indent=1))
