@@ -293,6 +293,12 @@ __device__ __forceinline__ GF hop_src(const HopParams &p, GF xc, GF xt, int64_t 
     return (GF)(((unsigned long long)hi << 32) | lo);
 }
 
+// the same pointer per lane (kernels whose lanes work on different hops: two / four hops per wave, hop slots)
+__device__ __forceinline__ GF hop_src_lane(const HopParams &p, GF xc, GF xt, int64_t k) {
+    const int64_t off = (k >= p.tail_hop_first) ? (k * (int64_t)p.step - p.tail_origin) : (k * (int64_t)p.step - p.in_origin);
+    return ((k >= p.tail_hop_first) ? xt : xc) + off;
+}
+
 constexpr int brev_c(int x, int bits) {
     int r = 0;
     for (int b = 0; b < bits; ++b) r |= ((x >> b) & 1) << (bits - 1 - b);

@@ -313,6 +313,8 @@ void plan_runs(const rc_engine *e, uint32_t n_channels, int64_t hop_count, uint3
         rounds = RC_ROUNDS_WAVE;
         if (e->tune_rounds > 0) rounds = (uint32_t)e->tune_rounds;
     }
+    // below N = 512 one workgroup (= one wave) of the fused generic kernel holds several runs (hop slots)
+    if (!independent_hops && !e->gen && e->log2n >= 5 && e->log2n <= 8) wg_per_cu *= (uint32_t)rc::hop_slots(e->log2n);
 #ifdef RC_WG_PER_CU
     wg_per_cu = RC_WG_PER_CU;  // tuning builds
 #endif

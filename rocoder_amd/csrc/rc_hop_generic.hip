@@ -195,22 +195,43 @@ constexpr HannG<LOG2N> make_hann_g() {
 template <int LOG2N>
 __device__ constexpr HannG<LOG2N> HANN_G = make_hann_g<LOG2N>();
 
+// Hop slots (round 4): below N = 512 a hop takes fewer than 64 threads (T = 32 / 16 / 8 / 4 at N = 256 / 128 / 64 / 32), and a
+// workgroup of T threads left most of its one wave idle. The fused path now packs SLOTS = 64 / T runs into one wave:
+// thread = (slot, t), every slot its own run of hops, LDS region, phase keys and source pointers (per lane: nothing is
+// forced uniform); the workgroup is one wave, so its barriers only order the wave's own LDS traffic.
+template <int LOG2N, int MODE>
+constexpr int hop_slots_of() { return (MODE == MODE_FUSED && Geo<LOG2N>::T < 64) ? 64 / Geo<LOG2N>::T : 1; }
+
 template <int LOG2N, int MODE, bool PITCH1, bool HANN = false>
-__global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(const HopParams p) {
+__global__ __launch_bounds__((Geo<LOG2N>::T * hop_slots_of<LOG2N, MODE>()), Geo<LOG2N>::WPS) void hop_kernel(const HopParams p) {
     using G = Geo<LOG2N>;
     constexpr int P = G::P, T = G::T, M = G::M, N = G::N, H = M;
     constexpr int LL = last_lor<G>(G::m);
-    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    constexpr int SLOTS = hop_slots_of<LOG2N, MODE>();
+    extern __shared__ __attribute__((aligned(16))) float2 lds_all[];
     ThreadCtx<G> ctx;
-    ctx.tid = threadIdx.x;
+    ctx.tid = SLOTS > 1 ? (int)(threadIdx.x % T) : (int)threadIdx.x;
     fill_lds_bases<G, G::m>(ctx);
     const int tid = ctx.tid;
-    const uint32_t run = blockIdx.x % p.runs_per_channel;
-    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    const uint32_t slot = SLOTS > 1 ? threadIdx.x / T : 0u;
+    float2 *lds = lds_all + (size_t)slot * G::LDS_FLOAT2;
+    uint32_t gidx = blockIdx.x;  // run index over all channels
+    bool live = true;
+    if constexpr (SLOTS > 1) {
+        gidx = blockIdx.x * SLOTS + slot;
+        live = gidx < p.runs_per_channel * p.n_channels;
+        if (!live) gidx = 0;
+    }
+    const uint32_t run = gidx % p.runs_per_channel;
+    const uint32_t ch = gidx / p.runs_per_channel;
     const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
     int64_t k_end = k_begin + p.run_len;
     if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
-    if (k_begin >= k_end) return;
+    if constexpr (SLOTS > 1) {
+        if (!live) k_end = k_begin;  // an empty slot runs no iteration (its lanes stay with the wave)
+    } else {
+        if (k_begin >= k_end) return;
+    }
     GF xc = (GF)p.x + (size_t)ch * p.in_stride;
     GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
     const unsigned lane2 = 2u * (unsigned)tid;
@@ -276,7 +297,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
                 sbW = v2f{a0.y, a1.y};
                 cbE = v2f{e0.x, e1.x};
                 sbE = v2f{e0.y, e1.y};
-                GF src = hop_src(p, xc, xt, k);
+                GF src = SLOTS > 1 ? hop_src_lane(p, xc, xt, k) : hop_src(p, xc, xt, k);
                 float xr0[P], xr1[P];
 #pragma unroll
                 for (int q = 0; q < P; ++q) {
@@ -289,6 +310,13 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
                                    __builtin_elementwise_fma(v2f{HANN_G<LOG2N>.wc[q], HANN_G<LOG2N>.wc[q]}, cbW, half2));
                     v[q] = to_f2(v2f{xr0[q], xr1[q]} * wq);
                 }
+            } else if constexpr (SLOTS > 1) {  // load_hop with a per-lane source pointer (the slots' hops differ)
+                GF src = hop_src_lane(p, xc, xt, k);
+                GF win = per_hop(p.window);
+#pragma unroll
+                for (int q = 0; q < P; ++q)
+                    v[q] = make_float2((src + 2 * T * q)[lane2] * (win + 2 * T * q)[lane2],
+                                       (src + 2 * T * q)[lane2 + 1] * (win + 2 * T * q)[lane2 + 1]);
             } else {
                 load_hop<LOG2N>(v, p, xc, xt, per_hop(p.window), k, lane2);
             }
@@ -397,8 +425,10 @@ __global__ __launch_bounds__(Geo<LOG2N>::T, Geo<LOG2N>::WPS) void hop_kernel(con
 template <int LOG2N>
 hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
     using G = Geo<LOG2N>;
-    const dim3 grid(p.runs_per_channel * p.n_channels), block(G::T);
-    const size_t lds = sizeof(float2) * G::LDS_FLOAT2;
+    constexpr int SF = hop_slots_of<LOG2N, MODE_FUSED>();  // the fused path packs SF runs into one wave (N < 512)
+    const uint32_t total_runs = p.runs_per_channel * p.n_channels;
+    const dim3 grid(mode == MODE_FUSED ? (total_runs + SF - 1) / SF : total_runs), block(mode == MODE_FUSED ? G::T * SF : G::T);
+    const size_t lds = sizeof(float2) * G::LDS_FLOAT2 * (mode == MODE_FUSED ? SF : 1);
     switch (mode) {
         case MODE_FUSED:
             if constexpr (LOG2N == 14) return launch_hop16k(p, s);  // hop4_kernel / hop2_kernel (rc_hop16k.hip)
@@ -442,6 +472,12 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
 
 int hop_workgroups_per_cu(int log2n, bool default_window) {
     return (log2n == 14 && default_window) ? 3 : 0;  // hop4_kernel: three workgroups per CU
+}
+
+int hop_slots(int log2n) {  // runs per workgroup of the fused generic kernel (hop_kernel: one wave holds 64 / T runs below N = 512)
+    if (log2n < 5 || log2n > 8) return 1;
+    const int M = 1 << (log2n - 1), T = cmax(M / RC_PMAX, cmin(64, M / 4));
+    return T < 64 ? 64 / T : 1;
 }
 
 int hop_resident_workgroups(int log2n, bool default_window) {

@@ -684,10 +684,6 @@ __global__ __launch_bounds__(64, RC_HOPW11_WPS) void hopw11_kernel(const HopPara
 // The hop index, the phase key, the source pointer and the store offsets are per lane. Overlap-add across the halves:
 // the upper half's head takes the lower half's tail of the same iteration, the lower half's head the upper half's tail of
 // the iteration before - one v_permlane32_swap per register moves both.
-__device__ __forceinline__ GF hop_src_lane(const HopParams &p, GF xc, GF xt, int64_t k) {
-    const int64_t off = (k >= p.tail_hop_first) ? (k * (int64_t)p.step - p.tail_origin) : (k * (int64_t)p.step - p.in_origin);
-    return ((k >= p.tail_hop_first) ? xt : xc) + off;
-}
 template <int PITCHC>
 __global__ __launch_bounds__(64, 3) void hopw10_kernel(const HopParams p) {
     constexpr int LOG2N = 10, m = 9, T = 32, P = 16, PH = 8, RES = 64, NS = 8;

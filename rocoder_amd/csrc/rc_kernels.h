@@ -165,6 +165,8 @@ int hop_workgroups_per_cu(int log2n, bool default_window);
 // Workgroups per CU of the wave-local kernels (rc_hopw.hip: N = 4096 / 8192 with the default window), 0 otherwise:
 // all runs are equally long, so the planner launches whole multiples of what is resident at once.
 int hop_resident_workgroups(int log2n, bool default_window);
+// Runs that share one workgroup (= one wave) of the fused generic kernel: 64 / T below N = 512, else 1.
+int hop_slots(int log2n);
 // Launchers. Return hipSuccess or the launch error. log2n in [5, 14].
 hipError_t launch_hop(int log2n, HopMode mode, const HopParams &p, hipStream_t s);
 // (between translation units) the N = 16384 fused path: rc_hop16k.hip, and rc_hop16k_prev.hip in the test-hook library

@@ -8,6 +8,7 @@
 //   kernel launches compute NOTHING (outputs stay zero): results are not checked here, only the host logic.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -153,6 +154,11 @@ int hop_workgroups_per_cu(int log2n, bool default_window) { return log2n == 14 ?
 int hop_resident_workgroups(int log2n, bool default_window) {
     if (!default_window) return 0;
     return log2n == 13 ? 6 : log2n == 12 ? 12 : (log2n >= 9 && log2n <= 11) ? 16 : 0;
+}
+int hop_slots(int log2n) {
+    if (log2n < 5 || log2n > 8) return 1;
+    const int M = 1 << (log2n - 1), T = std::max(M / 32, std::min(64, M / 4));
+    return T < 64 ? 64 / T : 1;
 }
 hipError_t launch_hop(int, HopMode, const HopParams &, hipStream_t) { return hipSuccess; }
 hipError_t launch_hop16k(const HopParams &, hipStream_t) { return hipSuccess; }
