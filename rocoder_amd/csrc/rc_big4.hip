@@ -176,7 +176,7 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
 //  * input rows are fetched in butterfly-pair order (0, R/2, 1, R/2 + 1, ...) with stage 0 inside the load loop, as a
 //    two-deep pipeline of 16-row batches (8 rows: flat, 32 rows = everything in flight: +1.5 %)
 //  * thread identities are re-derived per phase from an opaque copy of the thread id (hoisted they are spilled)
-constexpr int BIG4_OVL_K = 4, BIG4_PIPE_ROWS = 16, BIG4_EPI_BATCH = 4, BIG4_TAIL_LDS = 5;
+constexpr int BIG4_OVL_K = 4, BIG4_PIPE_ROWS = 16, BIG4_EPI_BATCH = 4, BIG4_TAIL_LDS = 5;  // (4 / 3 / 2 tail pairs in LDS: no spill either since round 4, and no faster: 5.37-5.39 vs 5.38-5.41 ms)
 constexpr int BIG4_T = 512;
 constexpr int BIG4_XBUF = 16400;  // exchange buffer, float2 slots (16384 + the 15 of the E1 / E3 index map)
 // tables behind the buffer: W_M^r [TA], W_N^r [TR] for r <= RES/2, thread 0's second twiddle base

@@ -111,6 +111,38 @@ def test_stretch_matches_oracle(N, L, f, p, ch):
         assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}")
 
 
+@pytest.mark.parametrize("N,f,p,ch,L", [(32, 2.0, 1, 3, 5000), (64, 4.0, 1, 2, 20000), (64, 1.5, 2, 1, 777),
+                                        (128, 8.0, 3, 5, 30001), (256, 4.0, 1, 2, 50000), (256, 2.0, 2, 7, 9999),
+                                        (128, 0.3, 1, 2, 20000), (64, 2.0, 1, 9, 100)])
+@pytest.mark.parametrize("table_window", [False, True])
+def test_hop_slots_below_512(N, f, p, ch, L, table_window):
+    """Below N = 512 a hop takes fewer than 64 threads and one wave of the generic fused kernel holds 64 / T runs side
+    by side (hop slots: per-slot LDS region, phase key, source pointer): channel counts and lengths that leave slots
+    empty or ragged, pitches, the computed default window and a caller's table window."""
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, L) for c in range(ch)])
+    if not table_window:
+        got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=3)
+        ref = oc.stretch_offline(x, N, f, 1.0, p, seed=3)
+    else:
+        w = (oc.hanning(N).astype(np.float64) ** 1.5).astype(np.float32)
+        with ra.Engine(window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=3, window=w) as e:
+            got = e.stretch_host(x)
+        chans = []
+        for c in range(ch):
+            st = oc.Stretcher(channels=ch, factor=f, pitch_multiple=p, window=w, seed=3, channel_index=c)
+            st.send(x[c])
+            st.close_input()
+            wins = []
+            while not st.is_done():
+                wins.append(st.next_window())
+            chans.append(np.concatenate(wins))
+        ref = np.stack(chans)
+    assert got.shape == ref.shape
+    for c in range(ch):
+        assert_parity(got[c], ref[c], f"slots N={N} ch{c}", reg=REG_TOL if f >= 0.5 else 5e-6)
+
+
 @pytest.mark.parametrize("N,L", [(256, 0), (256, 1), (256, 255), (256, 256), (256, 257),
                                  (1024, 1023), (16384, 16384), (16384, 20001),
                                  # the wave-local kernels: one hop, two hops, an odd count for the two-hops-per-wave ones
