@@ -166,6 +166,16 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
         if (RC_B4_ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
         else BIG4_BAR();                                                        \
     } while (0)
+#define BIG4_BAR_E2()                                                           \
+    do {                                                                        \
+        if (RC_B4_ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+        else BIG4_BAR_MID();                                                    \
+    } while (0)
+#define BIG4_BAR_E3()                                                           \
+    do {                                                                        \
+        if (RC_B4_ABL & 64) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+        else BIG4_BAR_MID();                                                    \
+    } while (0)
 // R = 64 (BASELINE C5): what the measurements of rounds 2-4 settled (docs/LAB_NOTES, DESIGN.md 5.4, profiles/r04a_c5_ablations.txt)
 //  * the last inverse stage (the one that pairs head sample q with tail sample q + PH) is computed inside the
 //    epilogue, one register pair at a time with its twiddle rebuilt on the spot, instead of inside I3 with 16
@@ -443,13 +453,13 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             const int b2s = lf | (uu << 10);
 #pragma unroll
             for (int rnd = 0; rnd < G; ++rnd) {
-                BIG4_BAR_MID();
+                BIG4_BAR_E2();
 #pragma unroll
                 for (int kk = 0; kk < 32; ++kk) {
                     if (R == 32) lds[b2s + (kk << 5)] = to_f2(w[kk]);
                     else lds[b2s + ((kk >> 4) << 5) + ((kk & 15) << 6)] = to_f2(w[32 * (kk >> 4) + 16 * rnd + (kk & 15)]);
                 }
-                BIG4_BAR_MID();
+                BIG4_BAR_E2();
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     if (R == 64 && ((s & 1) != rnd)) continue;
@@ -555,7 +565,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             const int tid = ptid(), l4 = tid & 15, hi = tid >> 4;
 #pragma unroll
             for (int rnd = 0; rnd < G; ++rnd) {
-                BIG4_BAR_MID();
+                BIG4_BAR_E3();
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     if (R == 64 && ((s & 1) != rnd)) continue;
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
                     for (int q = 0; q < 16; ++q) lds[base + q] = to_f2(st[s][q]);
                 }
-                BIG4_BAR_MID();
+                BIG4_BAR_E3();
 #pragma unroll
                 for (int kk = 0; kk < 32; ++kk) {
                     // R = 32: register kk = P4..P8; R = 64: kk = (group g = P14) << 4 | (P5..P8), P4 = rnd
