@@ -862,9 +862,23 @@ int run(int argc, char **argv) {
 
 }  // namespace
 
+// ROCODER_CLI_TIMING: the resident-set high-water mark of THIS program image (VmHWM of /proc/self/status: getrusage's
+// ru_maxrss also carries the launching process's pages from between fork and exec)
+static void report_peak_rss() {
+    if (!getenv("ROCODER_CLI_TIMING")) return;
+    FILE *f = fopen("/proc/self/status", "r");
+    if (!f) return;
+    char line[256];
+    while (fgets(line, sizeof line, f))
+        if (strncmp(line, "VmHWM:", 6) == 0) fprintf(stderr, "[timing] peak_rss_kib %ld\n", strtol(line + 6, nullptr, 10));
+    fclose(f);
+}
+
 int main(int argc, char **argv) {
     try {
-        return run(argc, argv);
+        const int rc = run(argc, argv);
+        report_peak_rss();
+        return rc;
     } catch (const std::exception &e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -1515,11 +1515,13 @@ int stream_enqueue(rc_engine *e, uint32_t channel, uint64_t nwin, int blk) {
 // The window the next hand-out of the channel delivers, computing / waiting as needed: *win points into the
 // channel's pinned block (valid until the next hand-out of the same channel).
 int stream_next(rc_engine *e, uint32_t channel, const float **win) {
-    int rc = check_device_error(e);
-    if (rc) return rc;
+    int rc;
     Channel &c = e->ch[channel];
     const uint32_t wout = e->par.window_out_len;
     if (c.ready_pos == c.ready_n) {
+        // (the device error word is looked at once per batch, not per window: it lives in mapped host memory, and an
+        // atomic exchange there costs about a microsecond - more than handing a window out)
+        if ((rc = check_device_error(e))) return rc;
         if (c.ahead_n) {  // the look-ahead batch: wait for its copy, make its block the current one
             RC_HIP(hipEventSynchronize(c.blk_ev[c.cur ^ 1]));
             c.cur ^= 1;

@@ -75,13 +75,14 @@ def test_cli_streams_the_output_file_with_bounded_memory(tmp_path):
     files, peak = {}, {}
     for name, env in (("stream", {}), ("collect", {"ROCODER_CLI_COLLECT": "1"})):
         out = str(tmp_path / f"{name}.wav")
-        p = subprocess.Popen([CLI, "-i", wav, "-o", out, "-w", "16384", "-f", "8", "--seed", "3"],
-                             env=dict(os.environ, **env), stderr=subprocess.PIPE)
-        _, status, ru = os.wait4(p.pid, 0)
-        assert status == 0, p.stderr.read()
-        p.stderr.close()
-        p.returncode = 0  # (reaped by wait4 above)
-        peak[name] = ru.ru_maxrss * 1024  # Linux: KiB
+        # the CLI reports the high-water mark of its own image (VmHWM): ru_maxrss of wait4 would also count this test
+        # process's pages from between fork and exec
+        r = subprocess.run([CLI, "-i", wav, "-o", out, "-w", "16384", "-f", "8", "--seed", "3"],
+                           env=dict(os.environ, ROCODER_CLI_TIMING="1", **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        hwm = [ln for ln in r.stderr.splitlines() if "peak_rss_kib" in ln]
+        assert hwm, r.stderr
+        peak[name] = int(hwm[-1].split()[-1]) * 1024
         files[name] = out
     a, b = open(files["stream"], "rb").read(), open(files["collect"], "rb").read()
     assert len(a) > 400e6 and a == b
