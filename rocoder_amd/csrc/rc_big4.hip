@@ -187,7 +187,7 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
 //  * input rows are fetched in butterfly-pair order (0, R/2, 1, R/2 + 1, ...) with stage 0 inside the load loop, as a
 //    two-deep pipeline of 16-row batches (8 rows: flat, 32 rows = everything in flight: +1.5 %)
 //  * thread identities are re-derived per phase from an opaque copy of the thread id (hoisted they are spilled)
-constexpr int BIG4_OVL_K = 4, BIG4_PIPE_ROWS = 16, BIG4_EPI_BATCH = 4, BIG4_TAIL_LDS = 5;  // (4 / 3 / 2 tail pairs in LDS: no spill either since round 4, and no faster: 5.37-5.39 vs 5.38-5.41 ms)
+constexpr int BIG4_OVL_K = 4, BIG4_PIPE_ROWS = 16, BIG4_EPI_BATCH = 16, BIG4_TAIL_LDS = 5;  // (epilogue batches of 2 / 4 / 8 / 16 pairs: 5.37 / 5.355 / 5.325 / 5.313 ms on one box)  // (4 / 3 / 2 tail pairs in LDS: no spill either since round 4, and no faster: 5.37-5.39 vs 5.38-5.41 ms)
 constexpr int BIG4_T = 512;
 constexpr int BIG4_XBUF = 16400;  // exchange buffer, float2 slots (16384 + the 15 of the E1 / E3 index map)
 // tables behind the buffer: W_M^r [TA], W_N^r [TR] for r <= RES/2, thread 0's second twiddle base
@@ -722,7 +722,9 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
             const int64_t g0 = k * (int64_t)H;
             GFW dst = outc + (g0 / (int64_t)pitch - p.out_origin);
             const uint32_t kr = (uint32_t)(g0 % pitch);
-            constexpr int EB = R > 32 ? BIG4_EPI_BATCH : 8;  // batch of table loads / window values in flight (register budget)
+            // batch of window values / table loads in flight (register budget): 16 pairs for the BASELINE C5 instantiation,
+            // 4 where the window comes from its table or the store decimates (those spill at 16)
+            constexpr int EB = R > 32 ? ((HANN && PITCH1) ? BIG4_EPI_BATCH : 4) : 8;
 #pragma unroll
             for (int q0 = 0; q0 < PH; q0 += EB) {
                 float wr0[EB], wr1[EB], wt0[EB], wt1[EB], e0[EB], e1[EB];
