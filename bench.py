@@ -385,6 +385,55 @@ def main():
             yh = eng.stretch_host(xh)
             extras["e2e_pcie_Msamples_s"] = yh.size / (time.perf_counter() - t_e) / 1e6
             del xh, yh
+            # the other single-GPU BASELINE configs, timed the same way (pre-heated, median of the engine's per-launch
+            # event times) so that the driver's own run carries them: C3 (pitch 3) and C5 (8 ch, window 65536, f = 32)
+            other = {}
+            try:
+                with torch.cuda.stream(stream):
+                    def timed_config(xx, **kw):
+                        e2 = rocoder_amd.Engine(sample_rate=SAMPLE_RATE, channels=xx.shape[0], seed=SEED, device=dev_index, **kw)
+                        o2 = torch.empty((xx.shape[0], e2.output_len(xx.shape[1])), dtype=torch.float32, device=device)
+                        e2.stretch_tensor(xx, out=o2)
+                        th = time.perf_counter()
+                        while time.perf_counter() - th < 0.7:
+                            for _ in range(4):
+                                e2.stretch_tensor(xx, out=o2)
+                            stream.synchronize()
+                        clk2, stop2 = [], threading.Event()
+
+                        def samp():
+                            while not stop2.is_set():
+                                try:
+                                    clk2.append(float(torch.cuda.clock_rate(dev_index)))
+                                except Exception:  # noqa: BLE001
+                                    return
+                                time.sleep(0.05)
+
+                        t2 = threading.Thread(target=samp, daemon=True)
+                        t2.start()
+                        for _ in range(40):
+                            e2.stretch_tensor(xx, out=o2)
+                        stream.synchronize()
+                        stop2.set()
+                        t2.join(timeout=2.0)
+                        ms2 = statistics.median(e2.kernel_times(10))
+                        _, hops2, _ = e2.last_kernel_stats()
+                        nwin = kw["window_len"]
+                        r2 = {"kernel_ms": round(ms2, 4), "hops": int(hops2),
+                              "out_Msamples_s": round(o2.numel() / ms2 / 1e3, 1),
+                              "frac_hbm_read": round(hops2 * 4.0 * nwin / ms2 / 1e6 / HBM_PEAK_GBS, 4),
+                              "sclk_mhz_under_load": round(statistics.median(clk2), 1) if clk2 else None}
+                        e2.close()
+                        del o2
+                        return r2
+
+                    other["C3_pitch3"] = timed_config(x, window_len=WINDOW, factor=FACTOR, pitch_multiple=3)
+                    x5 = synth_on_device(torch, device, 8, 5_292_000)
+                    other["C5_8ch_window65536_f32"] = timed_config(x5, window_len=65536, factor=32.0)
+                    del x5
+            except Exception as ex:  # noqa: BLE001
+                other["error"] = f"{type(ex).__name__}: {ex}"[:300]
+            extras["other_configs"] = other
 
     res = None
     if rank == 0:
@@ -499,6 +548,8 @@ def main():
             res["config"]["strong"] = strong
         if "e2e_pcie_Msamples_s" in extras:
             res["config"]["e2e_pcie_Msamples_s"] = round(extras["e2e_pcie_Msamples_s"], 1)
+        if "other_configs" in extras:  # not the metric's config: BASELINE configs[2] and configs[4] on this one GPU
+            res["config"]["other_configs"] = extras["other_configs"]
         if world == 1 and not args.no_cpu_baseline:
             one, many = cpu_baselines()
             res["cpu_baseline"] = one
