@@ -169,7 +169,8 @@ static void multi(const std::vector<int32_t> &devs, uint32_t N, float f, int p, 
         CHECK(got == n_out);
     }
     CHECK(rc_multi_stretch_device(m, (uint32_t)devs.size(), d_in, L, L, d_out, n_out, n_out, &got, nullptr) == RC_EINVAL);
-    CHECK(rc_multi_stretch_device(m, 0, x[0].data(), L, L, d_out, n_out, n_out, &got, nullptr) == RC_EINVAL);  // host pointer
+    if (L)  // (an empty input is never read: its pointer is not looked at)
+        CHECK(rc_multi_stretch_device(m, 0, x[0].data(), L, L, d_out, n_out, n_out, &got, nullptr) == RC_EINVAL);  // host pointer
     hipFree(d_in);
     hipFree(d_out);
     rc_engine_destroy(probe);
@@ -208,6 +209,8 @@ int main() {
     multi({0, 1, 2}, 16384, 8.0f, 3, 3, 200000);
     multi({2, 0, 0, 1, 3, 3, 1, 2}, 1024, 2.0f, 2, 1, 50000);
     multi({1}, 65536, 32.0f, 1, 8, 150000);
+    multi({0, 0}, 1024, 2.0f, 1, 2, 0);       // empty input: one window of silence per channel
+    multi({0, 1, 0}, 1024, 2.0f, 1, 1, 700);  // shorter than a window, more devices than windows
     // two engines driven from two threads at once (separate handles are independent)
     std::thread a([] { offline(4096, 4.0f, 1, 2, 120000, gain_kernel, 2); });
     std::thread b([] { seam(8192, 4.0f, 1, 2, 150000, 16, 1); });

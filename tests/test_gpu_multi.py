@@ -50,6 +50,24 @@ def test_multi_device_equals_one_engine_bit_for_bit(n_dev, N, f, p, ch, L):
     assert np.array_equal(got_d2, one)
 
 
+@pytest.mark.parametrize("L,n_dev", [(0, 2), (700, 3), (1024, 8), (1500, 4)])
+def test_multi_device_edge_lengths(L, n_dev):
+    """Empty input, input shorter than a window, more devices than windows: the same bits as one engine, host and
+    device form, in place and staged."""
+    import torch
+
+    ra = _ra()
+    x = np.stack([onp.synth_input(c, L) for c in range(2)]) if L else np.zeros((2, 0), np.float32)
+    with ra.Engine(window_len=1024, factor=2.0, channels=2, seed=5) as e:
+        one = e.stretch_host(x)
+    with ra.MultiEngine([0] * n_dev, window_len=1024, factor=2.0, channels=2, seed=5) as m:
+        assert np.array_equal(m.stretch_host(x), one)
+        xt = torch.from_numpy(x).cuda() if L else torch.zeros((2, 0), device="cuda")
+        assert np.array_equal(m.stretch_tensor(xt, root=n_dev - 1).cpu().numpy(), one)
+        m.set_staging(True)
+        assert np.array_equal(m.stretch_tensor(xt, root=0).cpu().numpy(), one)
+
+
 def test_multi_device_refuses_a_host_kernel_and_a_bad_root():
     ra = _ra()
     from rocoder_amd import _lib
