@@ -224,14 +224,16 @@ __global__ __launch_bounds__((Geo<LOG2N>::T * hop_slots_of<LOG2N, MODE>()), Geo<
     }
     const uint32_t run = gidx % p.runs_per_channel;
     const uint32_t ch = gidx / p.runs_per_channel;
-    const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
-    int64_t k_end = k_begin + p.run_len;
+    int64_t k_begin_ = p.hop_first + (int64_t)run * p.run_len;
+    int64_t k_end = k_begin_ + p.run_len;
     if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
     if constexpr (SLOTS > 1) {
-        if (!live) k_end = k_begin;  // an empty slot runs no iteration (its lanes stay with the wave)
+        if (!live || k_begin_ >= k_end) k_begin_ = k_end = 0;  // an empty slot runs no iteration, not even the recomputed
+                                                               // predecessor hop (its lanes stay with the wave)
     } else {
-        if (k_begin >= k_end) return;
+        if (k_begin_ >= k_end) return;
     }
+    const int64_t k_begin = k_begin_;
     GF xc = (GF)p.x + (size_t)ch * p.in_stride;
     GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
     const unsigned lane2 = 2u * (unsigned)tid;
