@@ -59,7 +59,8 @@ struct Geo {
     static constexpr int m = LOG2N - 1;        // log2 of complex length
     static constexpr int M = 1 << m;           // complex points
     static constexpr int N = 2 * M;            // window length
-    static constexpr int T = cmax(M / RC_PMAX, cmin(64, M / 4));  // threads per workgroup
+    // threads per workgroup (= per hop slot below N = 512, where 8 points per thread mean three passes instead of four)
+    static constexpr int T = M <= 128 ? cmax(2, M / 8) : cmax(M / RC_PMAX, cmin(64, M / 4));
     static constexpr int WPS = T >= 512 ? 4 : 2;  // waves per SIMD the register budget targets
     static constexpr int P = M / T;            // points per thread
     static constexpr int B = clog2(P);         // index bits per pass

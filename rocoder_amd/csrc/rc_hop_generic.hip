@@ -478,7 +478,7 @@ int hop_workgroups_per_cu(int log2n, bool default_window) {
 
 int hop_slots(int log2n) {  // runs per workgroup of the fused generic kernel (hop_kernel: one wave holds 64 / T runs below N = 512)
     if (log2n < 5 || log2n > 8) return 1;
-    const int M = 1 << (log2n - 1), T = cmax(M / RC_PMAX, cmin(64, M / 4));
+    const int M = 1 << (log2n - 1), T = M <= 128 ? cmax(2, M / 8) : cmax(M / RC_PMAX, cmin(64, M / 4));
     return T < 64 ? 64 / T : 1;
 }
 
@@ -498,7 +498,7 @@ int hop_resident_workgroups(int log2n, bool default_window) {
 bool hop_geometry(int log2n, int *threads, size_t *lds_bytes) {
     if (log2n < 5 || log2n > 14) return false;
     const int m = log2n - 1, M = 1 << m;
-    const int T = cmax(M / RC_PMAX, cmin(64, M / 4));
+    const int T = M <= 128 ? cmax(2, M / 8) : cmax(M / RC_PMAX, cmin(64, M / 4));
     if (threads) *threads = T;
     if (lds_bytes) *lds_bytes = sizeof(float2) * (size_t)(M + (M >> 5) + 1);
     return true;

@@ -145,7 +145,7 @@ namespace rc {
 bool hop_geometry(int log2n, int *threads, size_t *lds_bytes) {
     if (log2n < 5 || log2n > 14) return false;
     const int M = 1 << (log2n - 1);
-    const int T = std::max(M / 32, std::min(64, M / 4));
+    const int T = M <= 128 ? std::max(2, M / 8) : std::max(M / 32, std::min(64, M / 4));
     if (threads) *threads = T;
     if (lds_bytes) *lds_bytes = sizeof(float2) * (size_t)(M + (M >> 5) + 1);
     return true;
@@ -157,7 +157,7 @@ int hop_resident_workgroups(int log2n, bool default_window) {
 }
 int hop_slots(int log2n) {
     if (log2n < 5 || log2n > 8) return 1;
-    const int M = 1 << (log2n - 1), T = std::max(M / 32, std::min(64, M / 4));
+    const int M = 1 << (log2n - 1), T = M <= 128 ? std::max(2, M / 8) : std::max(M / 32, std::min(64, M / 4));
     return T < 64 ? 64 / T : 1;
 }
 hipError_t launch_hop(int, HopMode, const HopParams &, hipStream_t) { return hipSuccess; }
