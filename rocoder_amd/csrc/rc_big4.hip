@@ -167,6 +167,11 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
         if (RC_B4_ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
         else BIG4_BAR();                                                        \
     } while (0)
+#define BIG4_BAR_ENTRY()  /* (bit 128: the entry barriers of E1 / E4 - what hop4's own-region scheme would drop) */ \
+    do {                                                                        \
+        if (RC_B4_ABL & 128) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        else BIG4_BAR();                                                        \
+    } while (0)
 #define BIG4_BAR_E2()                                                           \
     do {                                                                        \
         if (RC_B4_ABL & 32) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
                 // R = 64, two rounds: the LDS takes the 32 stores of a wave at ~50 cycles apiece while all eight waves
                 // store (80 B/clk per CU), so the second round's stores are issued one at a time between the butterflies
                 // of F2 on the first round's group instead of in front of a barrier
-                BIG4_BAR();
+                BIG4_BAR_ENTRY();
 #pragma unroll
                 for (int q = 0; q < 32; ++q) lds[b1s + q] = to_f2(v[q]);
                 BIG4_BAR();
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(BIG4_T, 2) void big4_kernel(const HopParams p) {
 #pragma unroll
                 for (int j = 0; j < 32; ++j) v[j] = grp[j];
             }
-            BIG4_BAR();
+            BIG4_BAR_ENTRY();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < 32; ++j) lds[b4s + (j << 4)] = to_f2(v[j]);
