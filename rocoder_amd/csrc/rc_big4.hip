@@ -159,7 +159,7 @@ __device__ __forceinline__ void dit_g(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f
 #ifndef RC_B4_ABL
 #define RC_B4_ABL 0  // timing-only ablations (`make variant`; results are wrong by construction): 1 no input loads,
                      // 4 no output stores, 8 the E2 and E3 barriers become fences (32: E2 only, 64: E3 only),
-                     // 16 no barrier at all - profiles/r04a_c5_ablations.txt
+                     // 128 the entry barriers of E1 / E4 become fences, 16 no barrier at all - profiles/r04a_c5_ablations.txt
 #endif
 // (timing-only, RC_B4_ABL bit 8: the E2 / E3 barriers become compiler fences - what desynchronised waves would buy)
 #define BIG4_BAR_MID()                                                          \
