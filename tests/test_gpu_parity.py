@@ -1009,6 +1009,40 @@ def test_c5_geometry_every_sample_vs_oracle():
     assert_blocks(got, ref, N // 2, "C5 geometry")
 
 
+def test_output_longer_than_2_to_the_31_samples():
+    """One channel whose OUTPUT has 2.24e9 samples (L = 280 000 000, window 16384, factor 8; 8.96 GB): the hops at the
+    start, on both sides of the 2^31-sample boundary and at the very end against the oracle's single-hop resynthesis
+    (64-bit hop / sample indices everywhere: a 2-hour stereo file at factor 8 gets there)."""
+    import torch
+
+    ra = _engine_mod()
+    N, f, L, seed = 16384, 8.0, 280_000_000, 77
+    H = N // 2
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    xt = torch.rand((1, L), device="cuda", generator=g) - 0.5
+    with ra.Engine(window_len=N, factor=f, channels=1, seed=seed) as e:
+        n_out = e.output_len(L)
+        assert n_out > 2 ** 31
+        out = e.stretch_tensor(xt)
+        torch.cuda.synchronize()
+        K, kb = n_out // H, (2 ** 31) // H
+        ks = [0, 1, 5000, kb - 2, kb - 1, kb, kb + 1, K // 2 + 12345, K - 2, K - 1]
+        # _spot_check indexes a host copy of the input: hand it the slices it needs through a lazy view
+        class _X:
+            size = L
+
+            def __getitem__(self, sl):
+                return xt[0, sl].cpu().numpy()
+
+        class _O:
+            def __getitem__(self, idx):
+                a, b = int(idx[0]), int(idx[-1]) + 1
+                return out[0, a:b].cpu().numpy()[np.asarray(idx) - a]
+
+        _spot_check(ra, _O(), _X(), N, f, 1, seed, ks, 0)
+
+
 def _host_threads():
     import os
 
