@@ -234,7 +234,7 @@ class ReFFT:
         self._h = lib().rco_refft_new(_fp(self.window), self.n)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (module globals are gone at interpreter shutdown)
             lib().rco_refft_free(self._h)
             self._h = None
 
@@ -272,7 +272,7 @@ class Stretcher:
             raise ValueError("invalid stretcher parameters (reference would assert or hang)")
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib().rco_stretcher_free(self._h)
             self._h = None
 

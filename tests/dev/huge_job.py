@@ -9,7 +9,10 @@ import rocoder_amd as ra
 from oracle import cbind as oc
 from oracle import oracle_np as onp
 
-N, f, L, seed = 16384, 8.0, 280_000_000, 77
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+f = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 280_000_000
+seed = 77
 H = N // 2
 g = torch.Generator(device="cuda"); g.manual_seed(3)
 xt = (torch.rand((1, L), device="cuda", generator=g) - 0.5)
@@ -21,6 +24,7 @@ with ra.Engine(window_len=N, factor=f, channels=1, seed=seed) as e:
     K = n_out // H
     d = onp.derive(N, f, 1.0, 1)
     step, amp = d["step"], np.float32(d["amp"])
+    assert n_out > 2 ** 31
     r = oc.ReFFT(oc.hanning(N))
     env = oc.hanning_crossfade_compensation(H)
     kb = (2 ** 31) // H
