@@ -206,7 +206,9 @@ int rc_engine_resynth(rc_engine *e, uint32_t channel, uint64_t hop, const float 
  * caller's layout (device form: hipMemcpyPeerAsync into the root device's tensor; host form: device -> the caller's
  * arrays). A host frequency kernel (rc_config::kernel) is RC_EUNSUPPORTED here: a stateful apply() sees its
  * channel's hops in order, which a cut job cannot promise; the curated device kernels work. rc_config::device is
- * ignored. A device may be listed more than once (then its engines share it). */
+ * ignored. A device may be listed more than once (then its engines share it). Threading as for an engine: one thread
+ * at a time per rc_multi handle; the handle owns one persistent worker thread per listed device beyond the first (created
+ * by rc_multi_create, joined by rc_multi_destroy), and the calling thread's current HIP device is restored on return. */
 typedef struct rc_shard {
     uint32_t device_index;        /* index into the device list */
     uint32_t ch_first, ch_count;  /* part of ONE channel, or a block of WHOLE channels */
