@@ -267,6 +267,7 @@ struct rc_engine {
         void *slot[kWorkers] = {};
         hipStream_t st[kWorkers] = {};
         hipEvent_t ev_start = nullptr;
+        int max_workers = kWorkers;  // (rc_multi: the listed devices' engines copy at the same time and share the host's cores)
     } hp;
 };
 
@@ -1624,7 +1625,7 @@ int host_copy(rc_engine *e, bool to_device, float *const *host, float *dev, size
     if (total == 0) return RC_OK;
     const size_t slot_floats = HP::kSlotBytes / sizeof(float);
     const size_t per_row = (n + slot_floats - 1) / slot_floats, n_chunks = per_row * C;
-    int workers = (int)std::min<size_t>(HP::kWorkers, n_chunks);
+    int workers = (int)std::min<size_t>((size_t)std::max(1, std::min(e->hp.max_workers, (int)HP::kWorkers)), n_chunks);
     workers = std::max(1, std::min<int>(workers, (int)std::max(1u, std::thread::hardware_concurrency())));
     if (total < ((size_t)4 << 20)) {  // small: the plain path (no threads)
         for (uint32_t c = 0; c < C; ++c) {
@@ -2004,6 +2005,9 @@ int rc_multi_create(const rc_config *cfg, const int32_t *device_ids, uint32_t n_
         if (int rc = rc_engine_create(&c, &e)) return rc;
         m->dev.push_back(device_ids[i]);
         m->eng.push_back(e);
+        // host form: every listed device's engine runs its copy workers at the same time
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        e->hp.max_workers = (int)std::max(1u, std::min<unsigned>(rc_engine::HostPipe::kWorkers, hw / n_devices));
     }
     m->d_in.resize(n_devices);
     m->d_out.resize(n_devices);
