@@ -117,6 +117,24 @@ def test_compute_fails_loudly_without_gpu():
         rocoder_amd.stretch(np.zeros((1, 4096), np.float32), window_len=1024)
 
 
+def test_abi4_entry_points_fail_with_status_codes_without_gpu():
+    """The entry points added with ABI 4 return status codes for bad arguments and, without a GPU, for the device:
+    no crash, no silent success (rc_multi_create fails like rc_engine_create: there is no CPU fallback)."""
+    L = _lib.lib()
+    assert L.rc_multi_set_staging(None, 1) == _lib.RC_EINVAL
+    ms, ns = C.c_float(0), C.c_float(0)
+    assert L.rc_calib_valu(0, None, 0, C.byref(ms), C.byref(ns)) == _lib.RC_EINVAL  # zero launches
+    assert L.rc_calib_valu(0, None, 1, None, None) == _lib.RC_EINVAL                # nowhere to write
+    p, n = C.POINTER(C.c_float)(), C.c_size_t(0)
+    assert L.rc_engine_next_window_view(None, 0, C.byref(p), C.byref(n)) == _lib.RC_EINVAL
+    if L.rc_device_count() > 0:
+        pytest.skip("a GPU is present: the rest is the no-device behaviour")
+    assert L.rc_calib_valu(0, None, 1, C.byref(ms), C.byref(ns)) < 0
+    with pytest.raises(_lib.RocoderError) as ei:
+        rocoder_amd.MultiEngine([0, 0], window_len=1024, factor=2.0, channels=1)
+    assert ei.value.code == _lib.RC_ENODEVICE
+
+
 def test_unsupported_window_is_reported_not_faked():
     cfg, _k = make_config(window_len=1001)  # odd lengths (even ones that are not a power of two run as DFTs)
     h = C.c_void_p()
