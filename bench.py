@@ -1,33 +1,40 @@
 #!/usr/bin/env python3
 """Benchmark of the stretch hot path on MI355X.
 
-A "step" is one whole pass of the hot path over one synthetic job already resident in HBM. At N = 1 the
-job is BASELINE.json configs[1] — stereo 44.1 kHz, window 16384, factor 8, pitch 1, L = 26 460 000
-samples per channel (600 s): 51 652 hops -> 423 133 184 output samples per step. At N > 1 it is ONE
-stereo job of N x L samples per channel cut by rocoder_amd.distributed.shard_plan into (channel, hop
-range) shards, one rank per GPU (N = 2: a channel per GPU; N = 4, 8: half / quarter channels; every
-rank recomputes the single hop before its range): per-GPU work is that of N = 1 (weak scaling) and the
-data path has no collective. `value` = output samples of all ranks / max-rank time of the timed steps,
-outputs left sharded in HBM; the cost of the one optional collective, the RCCL concat of the shards on
-rank 0, is measured in a second timed region and reported beside it (config.concat); at N > 1 BASELINE
-configs[4] (C5: 8 channels, window 65536) cut over the same ranks is timed as well (config.c5_sharded). Both
-extras run after the main line is complete, under a watchdog, so they can never cost the measurement.
-The metric names a FIXED workload ("16384-win f=8 stereo @1/2/4/8 GPU"), so a second timed region cuts the N = 1
-job itself (L = 26 460 000 per channel, whatever N is) over the N ranks with the same shard plan: config.strong =
-{ms_per_step, value_Msamples_s, ms_per_step_1gpu (the same job on this rank's GPU alone, same run),
-efficiency_vs_1gpu}. `scaling` stays "weak" for `value`; config.strong.scaling says "strong".
+A "step" is one whole pass of the hot path over one synthetic job already resident in HBM: BASELINE.json
+configs[1] - stereo 44.1 kHz, window 16384, factor 8, pitch 1, L = 26 460 000 samples per channel (600 s):
+51 652 hops -> 423 133 184 output samples per step. The metric names that FIXED job "@1/2/4/8 GPU", so at N > 1
+the SAME job is cut by rocoder_amd.distributed.shard_plan into (channel, hop range) shards, one rank per GPU
+(N = 2: a channel per GPU; N = 4, 8: half / quarter channels; every rank recomputes the single hop before its
+range) - `"scaling": "strong"`, total work fixed. `value` = output samples of the whole job / max-rank time of
+the timed steps, outputs left sharded in HBM, no data-path collective. N = 1 is the one-GPU job itself, so a
+scaling sweep's N = 1 point equals the single-GPU bench line.
+
+Launching: under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process is one rank. Without
+a launcher, `python bench.py --gpus N` (N > 1) starts its own ranks: BEFORE torch is imported or the GPU is
+touched it starts N fresh child processes of this file with the environment a launcher would give them (RANK,
+LOCAL_RANK, WORLD_SIZE, MASTER_ADDR=127.0.0.1, a free MASTER_PORT), relays rank 0's one JSON line and exits
+with the first non-zero exit code of a rank (never exec). A box with fewer than N GPUs gets a JSON line with an
+"error" field and a non-zero exit code, no traceback.
+
+After the main line is complete, under a watchdog (they can never cost the measurement), every leg agreeing
+across ranks that its set-up succeeded before any timed collective is entered:
+  config.weak        - ONE stereo job of N x L samples per channel cut the same way (per-GPU work that of N = 1)
+  config.ref_1gpu    - the fixed job on every rank's own GPU alone, in this run (max over ranks)
+  config.c5_sharded  - BASELINE configs[4] (8 channels, window 65536) cut over the same ranks
+  config.concat      - the path's one optional collective: the RCCL concat of the shards on rank 0
 
 The same JSON line carries
-  roofline     — the dominant kernel (the N = 16384 fused hop kernel) priced on SURVEY §8(d4)'s
-                 algorithmic READ bytes 4*N per hop against the 8 TB/s HBM peak; its duration is the
-                 MEDIAN of the per-launch HIP-event times the engine records around the kernel itself
+  roofline     - the dominant kernel (the N = 16384 fused hop kernel) priced on SURVEY 8(d4)'s
+                 algorithmic READ bytes 4*N per hop of rank 0's launch against the 8 TB/s HBM peak; its duration
+                 is the MEDIAN of the per-launch HIP-event times the engine records around the kernel itself
                  (rc_engine_kernel_times), after >= 2 s of back-to-back launches (steady clocks);
                  also against the copy bandwidth measured on this very device, and the total-traffic,
-                 compulsory and LDS-traffic figures of SURVEY §8 d3/d4;
-  cpu_baseline — the CPU path of the reference algorithm written for speed (oracle/
+                 compulsory and LDS-traffic figures of SURVEY 8 d3/d4;
+  cpu_baseline - the CPU path of the reference algorithm written for speed (oracle/
                  rocoder_cpu_baseline.c, "port": the Rust reference cannot be built here), one DSP thread
                  as in src/stretcher_processor.rs:55-71, on a bounded sample of the same workload;
-  cpu_baseline_all_cores — the same code on every core this process may use (rank 0, N = 1 only).
+  cpu_baseline_all_cores - the same code on every core this process may use (rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -155,6 +162,113 @@ def cpu_baselines(all_cores=True):
     return one, many
 
 
+METRIC = "output Msamples/s, 16384-win f=8 stereo (x CPU-realtime in config)"
+
+
+def error_line(args, msg):
+    """The bench contract's one JSON line when no measurement could be made (the caller exits non-zero)."""
+    return {"metric": METRIC, "value": None, "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "error": str(msg)[:600]}
+
+
+def gpus_on_this_box():
+    """GPU agents the kernel driver lists (KFD topology nodes with SIMDs), read from sysfs: no HIP call, no torch
+    import - this runs in the launcher process, which must never touch the GPU. None when the tree is not there."""
+    import glob
+
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            for ln in open(path):
+                k, _, v = ln.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            return None
+    return n
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (never exec: this
+    process has not touched the GPU and never will) with the environment torch.distributed.run would give them
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT), relay rank 0's one JSON line and return
+    the first non-zero exit code of a rank."""
+    import signal
+    import socket
+    import subprocess
+
+    rehearsal = os.environ.get("ROCODER_BENCH_REHEARSAL") in ("1", "hang")
+    have = gpus_on_this_box()
+    if have is not None and have < args.gpus and not rehearsal:
+        print(json.dumps(error_line(args, f"--gpus {args.gpus} but this box has {have} GPU(s) "
+                                          "(ROCODER_BENCH_REHEARSAL=1 walks the N-rank code on one GPU over gloo)")))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(),
+                                      start_new_session=True))
+    limit = float(os.environ.get("ROCODER_BENCH_SPAWN_TIMEOUT", "1500"))
+    t_end = time.monotonic() + limit
+    out = b""
+    rc = 0
+
+    def reap(grace):
+        """Wait for the ranks; once one has failed the others get `grace` seconds (a rank that lost its peers sits in
+        a collective for ever), then exactly the process groups started above are killed."""
+        nonlocal rc
+        deadline = None
+        while any(p.poll() is None for p in procs):
+            for p in procs:
+                if p.poll() not in (None, 0) and rc == 0:
+                    rc = p.returncode
+                    deadline = time.monotonic() + grace
+            now = time.monotonic()
+            if (deadline is not None and now > deadline) or now > t_end:
+                if rc == 0:
+                    rc = 124
+                for p in procs:
+                    if p.poll() is None:
+                        try:
+                            os.killpg(p.pid, signal.SIGKILL)
+                        except ProcessLookupError:
+                            pass
+                break
+            time.sleep(0.1)
+        for p in procs:
+            p.wait()
+            if p.returncode and rc == 0:
+                rc = p.returncode
+
+    import threading
+
+    reaper = threading.Thread(target=reap, args=(30.0,), daemon=True)
+    reaper.start()
+    out = procs[0].stdout.read()  # ends when rank 0 exits (or is killed by the reaper)
+    reaper.join()
+    line = None
+    for ln in out.decode(errors="replace").splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line is None:
+        line = json.dumps(error_line(args, f"the {args.gpus} ranks printed no result line (exit code {rc})"))
+        rc = rc or 1
+    print(line, flush=True)
+    return rc if 0 <= rc < 256 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,26 +278,58 @@ def main():
                     help="seconds of back-to-back launches before the timed steps (steady DVFS state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the copy microbench, the PCIe-inclusive run and the concat region")
+                    help="skip the copy microbench, the PCIe-inclusive runs and the post-measurement legs")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1:
+        print(json.dumps(error_line(args, "--gpus and --steps must be >= 1")))
+        return 2
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args, sys.argv[1:])  # torch not imported, GPU not touched in this process
 
     # Exactly ONE line on stdout (the JSON): RCCL / the HIP runtime print banners to fd 1, so park
     # the real stdout and point fd 1 at stderr until the result is ready.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    rank = int(os.environ.get("RANK", "0"))
+
+    def say(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
+    try:
+        return worker(args, say)
+    except SystemExit:
+        raise
+    except BaseException as ex:  # noqa: BLE001  (a failed measurement still owes the caller its one line)
+        import traceback
+
+        traceback.print_exc(file=sys.stderr)
+        if rank == 0:
+            say(error_line(args, f"{type(ex).__name__}: {ex}"))
+        return 1
+
+
+def worker(args, say):
+    import threading
 
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU fallback")
     # ROCODER_BENCH_REHEARSAL=1 (dev only, never the driver's command): every rank on cuda:0 over gloo, to walk the
     # N > 1 shard plan / timing code on a one-GPU box. RCCL refuses two ranks on one device, so the concat region
-    # reports an error there; the JSON line is marked "rehearsal" and is not a measurement.
+    # is skipped there; the JSON line is marked "rehearsal" and is not a measurement.
     rehearsal = os.environ.get("ROCODER_BENCH_REHEARSAL") in ("1", "hang")  # "hang": stall the concat region (watchdog test)
+    if world != args.gpus:
+        if rank == 0:
+            say(error_line(args, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)"))
+        return 2
+    n_dev = torch.cuda.device_count()  # (does not initialise the GPU)
+    if n_dev < 1 or (n_dev < world and not rehearsal):
+        if rank == 0:
+            say(error_line(args, f"--gpus {world} but this box has {n_dev} GPU(s): the engine has no CPU fallback"))
+        return 2
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -196,7 +342,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    red_device = "cpu" if rehearsal else device
 
     def note(msg):  # progress on stderr in rehearsals only
         if rehearsal:
@@ -205,22 +351,30 @@ def main():
     def max_over_ranks(v):
         if dist is None:
             return v
-        tt = torch.tensor([v], dtype=torch.float64, device="cpu" if rehearsal else device)
+        tt = torch.tensor([v], dtype=torch.float64, device=red_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    def all_ranks_ok(ok):
+        """Every rank calls this once per leg, whatever happened in its own set-up: the timed collectives of a leg
+        are entered by all ranks or by none (a rank that skips its barriers hangs the others)."""
+        if dist is None:
+            return ok
+        tt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=red_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        return float(tt.item()) > 0.5
+
     import rocoder_amd
     from rocoder_amd import _lib
-    from rocoder_amd.distributed import engine_compute, shard_plan, shard_view, stretch_sharded
+    from rocoder_amd.distributed import engine_compute, shard_plan, stretch_sharded
 
     kernel_id = _lib.lib().rc_kernel_id().decode()
-    # ONE job for all ranks: same seed, same (replicated, device-generated) input of world x L samples
-    length = L_IN * world
+    # ONE job for all ranks, the same at every N: same seed, same (replicated, device-generated) input
     eng = rocoder_amd.Engine(window_len=WINDOW, factor=FACTOR, pitch_multiple=PITCH,
                              sample_rate=SAMPLE_RATE, channels=CHANNELS, seed=SEED, device=dev_index)
-    x = synth_on_device(torch, device, CHANNELS, length)
+    x = synth_on_device(torch, device, CHANNELS, L_IN)
     wout = eng.params.window_out_len
-    n_out = eng.output_len(length)          # per channel, whole job
+    n_out = eng.output_len(L_IN)          # per channel, whole job
     nwin = n_out // wout
     plan = shard_plan(CHANNELS, nwin, world)
     mine = [s for s in plan if s.rank == rank]
@@ -245,10 +399,9 @@ def main():
     note(f"plan {[(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan]}")
     barrier()
     note("first barrier passed")
-    # shader clock under THIS load, sampled by a host thread while the pre-heat and the timed steps run (boxes of the
-    # pool hold 2.0 - 2.15 GHz under the hop kernel; the calibration kernel below alone does not show it)
-    import threading
-
+    # shader clock under THIS load, sampled by a host thread while the PRE-HEAT runs and stopped before the timed
+    # steps (an SMI query every 50 ms has no place inside the measurement it annotates). Boxes of the pool
+    # hold 2.0 - 2.15 GHz under the hop kernel; the calibration kernel below alone does not show it.
     clk_samples, clk_stop = [], threading.Event()
 
     def clk_sampler():
@@ -260,12 +413,12 @@ def main():
             time.sleep(0.05)
 
     clk_thread = threading.Thread(target=clk_sampler, daemon=True)
-    clk_thread.start()
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
             step()
         # pre-heat: >= preheat_s of back-to-back launches so the timed steps run at the clock the chip
         # holds under this load (MI355X_MICROARCH.md, DVFS), not at the boost clock of an idle chip
+        clk_thread.start()
         t_heat = time.perf_counter()
         n_heat = 0
         while time.perf_counter() - t_heat < args.preheat_s:
@@ -273,6 +426,11 @@ def main():
                 step()
             n_heat += 32
             stream.synchronize()
+        t_heat_end = time.perf_counter()
+        clk_stop.set()
+        clk_thread.join(timeout=2.0)
+        for _ in range(8):  # the join above left the chip idle for a moment
+            step()
         barrier()
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
@@ -287,15 +445,17 @@ def main():
         # engine's device error word; synchronize() raises it. A line measured on such a run must not be printed.
         eng.synchronize()
         step_event_ms = ev0.elapsed_time(ev1) / args.steps
-        # per-launch kernel durations of exactly those steps (the engine brackets each kernel launch)
-        per_call = eng.kernel_times(min(64, args.steps * max(1, len(mine))))
-        kernel_ms_median = statistics.median(per_call)
-        kernel_ms_mean = sum(per_call) / len(per_call)
+        # per-launch kernel durations of exactly those steps (the engine brackets each kernel launch); a step of a
+        # rank that holds several shards is the sum of its launches
+        per_step = max(1, len(mine))
+        k_steps = max(1, min(64 // per_step, args.steps))
+        per_call = eng.kernel_times(k_steps * per_step)
+        per_call = per_call[len(per_call) % per_step:]
+        per_step_ms = [sum(per_call[i:i + per_step]) for i in range(0, len(per_call), per_step)]
+        kernel_ms_median = statistics.median(per_step_ms)
+        kernel_ms_mean = sum(per_step_ms) / len(per_step_ms)
     note(f"timed region done: {dt:.4f} s")
-    clk_stop.set()
-    clk_thread.join(timeout=2.0)
-    t_end = t0 + dt
-    clk_under_load = [c for (tt, c) in clk_samples if t_end - 1.0 <= tt <= t_end]
+    clk_under_load = [c for (tt, c) in clk_samples if t_heat_end - 1.0 <= tt <= t_heat_end]
     sclk_mhz = statistics.median(clk_under_load) if clk_under_load else None
     dt = max_over_ranks(dt)
 
@@ -312,56 +472,7 @@ def main():
     except Exception as ex:  # noqa: BLE001
         calib = {"error": f"{type(ex).__name__}: {ex}"[:200]}
 
-    # ---- strong scaling of the metric's fixed job: the N = 1 job cut N ways
-    strong = None
-    if world > 1:
-        try:
-            with torch.cuda.stream(stream):
-                xf = x[:, :L_IN]
-                n_out_f = eng.output_len(L_IN)
-                nwin_f = n_out_f // wout
-                plan_f = shard_plan(CHANNELS, nwin_f, world)
-                mine_f = [s for s in plan_f if s.rank == rank]
-                comp_f = engine_compute(eng, xf)
-                bufs_f = {s: torch.empty((s.ch_count, s.win_count * wout), dtype=torch.float32, device=device)
-                          for s in mine_f}
-                full_f = torch.empty((CHANNELS, n_out_f), dtype=torch.float32, device=device)
-                one_f = [s for s in shard_plan(CHANNELS, nwin_f, 1)]
-
-                def timed(fn, k):
-                    for _ in range(3):
-                        fn()
-                    barrier()
-                    t = time.perf_counter()
-                    for _ in range(k):
-                        fn()
-                    barrier()
-                    return max_over_ranks(time.perf_counter() - t) / k
-
-                ks = max(args.steps, 20)
-                t_n = timed(lambda: [comp_f(s, out=bufs_f[s]) for s in mine_f], ks)
-                # the same job on ONE GPU, in this run: every rank does the whole job on its own GPU (max over ranks)
-                t_1 = timed(lambda: [comp_f(s, out=full_f[s.ch_first:s.ch_first + s.ch_count]) for s in one_f], ks)
-                strong = {
-                    "scaling": "strong",
-                    "workload": f"BASELINE configs[1] at its own size (L={L_IN}/ch), cut over {world} rank(s) by shard_plan",
-                    "steps": ks,
-                    "ms_per_step": round(t_n * 1e3, 4),
-                    "value_Msamples_s": round(float(n_out_f) * CHANNELS / t_n / 1e6, 1),
-                    "ms_per_step_1gpu": round(t_1 * 1e3, 4),
-                    "efficiency_vs_1gpu": round(t_1 / (world * t_n), 4),
-                    "hops_per_rank": sum(s.ch_count * s.win_count for s in mine_f) * eng.params.hops_per_window,
-                    "plan": [(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan_f],
-                    "note": "outputs left sharded in HBM, no collective; wall time between barriers, max over ranks, "
-                            "one kernel launch per shard per step (the per-step host cost is inside)",
-                }
-                del bufs_f, full_f
-        except Exception as ex:  # noqa: BLE001
-            strong = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-        note(f"strong leg: {strong}")
-
     extras = {}
-    concat = None
     if not args.no_extras:
         with torch.cuda.stream(stream):
             # device copy microbench on this very GPU: the measured bandwidth the roofline is also priced on
@@ -379,61 +490,8 @@ def main():
             extras["copy_GBs"] = 2.0 * 4.0 * n_copy * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
             del a, b
         if world == 1:
-            # PCIe-inclusive (host buffers in and out): never `value`, reported for SURVEY §8 d1
-            xh = x.cpu().numpy()
-            t_e = time.perf_counter()
-            yh = eng.stretch_host(xh)
-            extras["e2e_pcie_Msamples_s"] = yh.size / (time.perf_counter() - t_e) / 1e6
-            del xh, yh
-            # the other single-GPU BASELINE configs, timed the same way (pre-heated, median of the engine's per-launch
-            # event times) so that the driver's own run carries them: C3 (pitch 3) and C5 (8 ch, window 65536, f = 32)
-            other = {}
-            try:
-                with torch.cuda.stream(stream):
-                    def timed_config(xx, **kw):
-                        e2 = rocoder_amd.Engine(sample_rate=SAMPLE_RATE, channels=xx.shape[0], seed=SEED, device=dev_index, **kw)
-                        o2 = torch.empty((xx.shape[0], e2.output_len(xx.shape[1])), dtype=torch.float32, device=device)
-                        e2.stretch_tensor(xx, out=o2)
-                        th = time.perf_counter()
-                        while time.perf_counter() - th < 0.7:
-                            for _ in range(4):
-                                e2.stretch_tensor(xx, out=o2)
-                            stream.synchronize()
-                        clk2, stop2 = [], threading.Event()
-
-                        def samp():
-                            while not stop2.is_set():
-                                try:
-                                    clk2.append(float(torch.cuda.clock_rate(dev_index)))
-                                except Exception:  # noqa: BLE001
-                                    return
-                                time.sleep(0.05)
-
-                        t2 = threading.Thread(target=samp, daemon=True)
-                        t2.start()
-                        for _ in range(40):
-                            e2.stretch_tensor(xx, out=o2)
-                        stream.synchronize()
-                        stop2.set()
-                        t2.join(timeout=2.0)
-                        ms2 = statistics.median(e2.kernel_times(10))
-                        _, hops2, _ = e2.last_kernel_stats()
-                        nwin = kw["window_len"]
-                        r2 = {"kernel_ms": round(ms2, 4), "hops": int(hops2),
-                              "out_Msamples_s": round(o2.numel() / ms2 / 1e3, 1),
-                              "frac_hbm_read": round(hops2 * 4.0 * nwin / ms2 / 1e6 / HBM_PEAK_GBS, 4),
-                              "sclk_mhz_under_load": round(statistics.median(clk2), 1) if clk2 else None}
-                        e2.close()
-                        del o2
-                        return r2
-
-                    other["C3_pitch3"] = timed_config(x, window_len=WINDOW, factor=FACTOR, pitch_multiple=3)
-                    x5 = synth_on_device(torch, device, 8, 5_292_000)
-                    other["C5_8ch_window65536_f32"] = timed_config(x5, window_len=65536, factor=32.0)
-                    del x5
-            except Exception as ex:  # noqa: BLE001
-                other["error"] = f"{type(ex).__name__}: {ex}"[:300]
-            extras["other_configs"] = other
+            extras["e2e_pcie"] = e2e_host(eng, x, torch)
+            extras["other_configs"] = other_configs(torch, device, dev_index, stream, x, threading)
 
     res = None
     if rank == 0:
@@ -442,10 +500,10 @@ def main():
         H = WINDOW // 2
         step_len = eng.params.sample_step_len
         read_b, write_b = 4.0 * WINDOW, 4.0 * H / PITCH
-        algo_bytes = hops_mine * read_b  # 4N read bytes per hop, one launch of this rank
+        algo_bytes = hops_mine * read_b  # 4N read bytes per hop, one step's launches of this rank
         sec = kernel_ms_median * 1e-3
         achieved = algo_bytes / sec / 1e9
-        traffic, traffic_src = pmc_traffic(kernel_id)
+        traffic, traffic_src = pmc_traffic(kernel_id) if world == 1 else (None, "counters were taken on the N = 1 job")
         # LDS bytes per hop: four exchanges of N/2 complex points (8 B each), written once and read once
         lds_w = lds_r = 4 * (WINDOW // 2) * 8.0
         roof = {
@@ -456,12 +514,12 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
             "traffic_source": traffic_src,
-            "kernel": f"N=16384 fused hop kernel ({kernel_id})",
+            "kernel": f"N=16384 fused hop kernel ({kernel_id})" + ("" if world == 1 else f", rank 0's shard of the job ({hops_mine} hops)"),
             "kernel_id": kernel_id,
             "kernel_ms": round(kernel_ms_median, 4),
             "kernel_ms_mean": round(kernel_ms_mean, 4),
-            "kernel_ms_min": round(min(per_call), 4),
-            "kernel_ms_max": round(max(per_call), 4),
+            "kernel_ms_min": round(min(per_step_ms), 4),
+            "kernel_ms_max": round(max(per_step_ms), 4),
             "kernel_launches_timed": len(per_call),
             "step_event_ms": round(step_event_ms, 4),
             "preheat_launches": n_heat,
@@ -477,7 +535,7 @@ def main():
                     "of MI355X_MICROARCH.md. The kernel is VALU-pipe bound (FFT butterflies + per-bin hash/sincos), "
                     "see DESIGN.md §5",
         }
-        pv = pmc_valu(kernel_id)
+        pv = pmc_valu(kernel_id) if world == 1 else None
         if pv:
             # the counter-backed ceiling of this kernel: its VALU instruction stream at full
             # occupancy of the VALU pipe - what the kernel would run at if nothing but VALU issue ever stalled
@@ -500,7 +558,7 @@ def main():
         elif calib:
             roof["box_calib_error"] = calib.get("error")
         # the shader clock this box held under the load of the hop kernel (median of the SMI samples of the last second
-        # of pre-heat + timed steps) and the kernel time scaled to the reference clock
+        # of the pre-heat) and the kernel time scaled to the reference clock
         roof["sclk_mhz_under_load"] = sclk_mhz
         roof["sclk_samples"] = len(clk_under_load)
         if sclk_mhz:
@@ -511,7 +569,7 @@ def main():
             roof["measured_copy_GBs"] = round(extras["copy_GBs"], 1)
             roof["frac_measured_peak"] = round(achieved / extras["copy_GBs"], 4)
         res = {
-            "metric": "output Msamples/s, 16384-win f=8 stereo (x CPU-realtime in config)",
+            "metric": METRIC,
             "value": round(value, 1),
             "unit": "Msamples/s",
             "n_gpus": world,
@@ -519,36 +577,33 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo, not a measurement)",
             "config": {
                 "workload": f"BASELINE configs[1]: stereo 44.1 kHz, window=16384, factor=8, pitch=1, "
-                            f"L={length}/ch ({world} x 26460000), inputs resident in HBM; signal = BASELINE.md §3's "
-                            "0.5 sin(2 pi 220 (c+1) t) + 0.05 u_c[t] with u_c from torch.rand on the device "
+                            f"L={L_IN}/ch (the same fixed job at every N), inputs resident in HBM; signal = BASELINE.md "
+                            "§3's 0.5 sin(2 pi 220 (c+1) t) + 0.05 u_c[t] with u_c from torch.rand on the device "
                             "(seed 0xC0DEC0DE), NOT SURVEY d2's splitmix64 stream (the parity tests use that one; "
                             "throughput does not depend on the noise bits)",
-                "hops_per_step": hops_mine * world,
+                "hops_per_step": n_out * CHANNELS * PITCH // H,
                 "hops_per_rank": hops_mine,
                 "output_samples_per_step": n_out * CHANNELS,
                 "x_realtime": round(value * 1e6 / CHANNELS / SAMPLE_RATE, 1),
                 "parallelism": (f"{world} rank(s): one job cut into (channel, hop range) shards by shard_plan "
                                 f"{[(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan]}, "
-                                "outputs left sharded in HBM, no data-path collective"),
+                                "outputs left sharded in HBM, no data-path collective; one kernel launch per shard and "
+                                "step, wall time between barriers, max over ranks"),
             },
             "roofline": roof,
         }
-        if strong is None and world == 1:  # at N = 1 the main line IS the fixed job
-            strong = {"scaling": "strong", "workload": f"BASELINE configs[1] at its own size (L={L_IN}/ch): the main line",
-                      "steps": args.steps, "ms_per_step": round(dt / args.steps * 1e3, 4),
-                      "value_Msamples_s": round(value, 1), "ms_per_step_1gpu": round(dt / args.steps * 1e3, 4),
-                      "efficiency_vs_1gpu": 1.0}
-        if strong:
-            res["config"]["strong"] = strong
-        if "e2e_pcie_Msamples_s" in extras:
-            res["config"]["e2e_pcie_Msamples_s"] = round(extras["e2e_pcie_Msamples_s"], 1)
-        if "other_configs" in extras:  # not the metric's config: BASELINE configs[2] and configs[4] on this one GPU
+        if "e2e_pcie" in extras:
+            res["config"]["e2e_pcie"] = extras["e2e_pcie"]
+            best = extras["e2e_pcie"].get("pinned_Msamples_s") or extras["e2e_pcie"].get("pageable_reused_Msamples_s")
+            if best:
+                res["config"]["e2e_pcie_Msamples_s"] = best
+        if "other_configs" in extras:  # not the metric's config: BASELINE configs[2..4] on this one GPU
             res["config"]["other_configs"] = extras["other_configs"]
         if world == 1 and not args.no_cpu_baseline:
             one, many = cpu_baselines()
@@ -557,122 +612,234 @@ def main():
             if many:
                 res["cpu_baseline_all_cores"] = many
                 res["config"]["x_cpu_all_cores"] = round(value / many["value"], 1)
-    # ---- the one collective of the path, AFTER the main line is complete and under a watchdog: a concat that hangs
-    # (it is the only code here that a one-GPU box cannot rehearse) must not cost the measurement
 
+    # ---- post-measurement legs (N > 1 only): the main line is complete; everything below runs under a watchdog that
+    # prints the line and exits non-zero if a collective hangs, and every leg agrees across the ranks on its set-up
+    # before it enters a timed collective.
     lock = threading.Lock()
     emitted = [False]
+    legs = {}
 
     def emit():
         with lock:
             if rank == 0 and not emitted[0]:
-                if concat:
-                    res["config"]["concat"] = concat
-                if c5:
-                    res["config"]["c5_sharded"] = c5
-                os.write(real_stdout, (json.dumps(res) + "\n").encode())
+                res["config"].update(legs)
+                say(res)
             emitted[0] = True
 
     def watchdog():
         # The main line is printed (it is complete), then the process exits NON-ZERO: a collective that hung on
         # GPU-initialised processes must be visible to the launcher, not look like a clean run.
-        nonlocal concat
         with lock:
             if rank == 0 and not emitted[0]:
-                res["config"]["concat"] = concat or {
-                    "error": f"the post-measurement extras (C5 shards, concat) did not finish within "
-                             f"{CONCAT_TIMEOUT_S} s; the main line is unaffected"}
-                if c5:
-                    res["config"]["c5_sharded"] = c5
-                os.write(real_stdout, (json.dumps(res) + "\n").encode())
+                res["config"].update(legs)
+                res["config"]["legs_error"] = (f"the post-measurement legs did not finish within {CONCAT_TIMEOUT_S} s "
+                                               f"(finished: {sorted(legs)}); the main line is unaffected")
+                say(res)
             emitted[0] = True
         os._exit(3)
 
     timer = threading.Timer(CONCAT_TIMEOUT_S, watchdog)
     timer.daemon = True
-    if world > 1:
-        timer.start()
-    c5 = None
-    if not args.no_extras and dist is not None and world > 1:
-        # BASELINE configs[4] (C5: 8 channels, window 65536, factor 32, L = 5 292 000 per channel) cut over the
-        # ranks by the same shard_plan (8 ranks: one channel per GPU, no halo). Not the metric's config: it rides in
-        # config.c5_sharded, measured after the main line is complete.
+    broken = [False]
+
+    def leg(name, setup, body):
+        """setup() -> state on every rank (local work only: allocation, engines); then ONE agreement collective; then
+        body(state) -> dict with the leg's timed collectives, entered by every rank or by none."""
+        if broken[0]:
+            return
+        state, err = None, None
         try:
             with torch.cuda.stream(stream):
-                C5 = dict(window=65536, factor=32.0, channels=8, length=5_292_000)
-                eng5 = rocoder_amd.Engine(window_len=C5["window"], factor=C5["factor"], pitch_multiple=1,
-                                          sample_rate=SAMPLE_RATE, channels=C5["channels"], seed=SEED, device=dev_index)
-                x5 = synth_on_device(torch, device, C5["channels"], C5["length"])
-                wout5 = eng5.params.window_out_len
-                n_out5 = eng5.output_len(C5["length"])
-                nwin5 = n_out5 // wout5
-                plan5 = shard_plan(C5["channels"], nwin5, world)
-                mine5 = [s for s in plan5 if s.rank == rank]
-                comp5 = engine_compute(eng5, x5)
-                bufs5 = {s: torch.empty((s.ch_count, s.win_count * wout5), dtype=torch.float32, device=device)
-                         for s in mine5}
-                for _ in range(3):
-                    for s in mine5:
-                        comp5(s, out=bufs5[s])
-                barrier()
-                k5 = max(3, min(10, args.steps))
-                t5 = time.perf_counter()
-                for _ in range(k5):
-                    for s in mine5:
-                        comp5(s, out=bufs5[s])
-                barrier()
-                dt5 = max_over_ranks(time.perf_counter() - t5)
-                c5 = {
-                    "workload": "BASELINE configs[4]: 8 ch, window=65536, factor=32, L=5292000/ch, one job cut by shard_plan",
-                    "steps": k5,
-                    "ms_per_step": round(dt5 / k5 * 1e3, 4),
-                    "value_Msamples_s": round(float(n_out5) * C5["channels"] * k5 / dt5 / 1e6, 1),
-                    "plan": [(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan5],
-                }
-                del bufs5, x5
-                eng5.close()
+                state = setup()
+                torch.cuda.synchronize(device)
         except Exception as ex:  # noqa: BLE001
-            c5 = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-        note(f"c5 extra: {c5}")
-    if not args.no_extras:
-        with torch.cuda.stream(stream):
-            if dist is not None and world > 1 and rehearsal:
-                concat = {"skipped": "rehearsal: gloo has no device-to-device send/recv"}
-                if os.environ.get("ROCODER_BENCH_REHEARSAL") == "hang":
-                    concat = None
-                    time.sleep(1e6)
-            elif dist is not None and world > 1:
-                # the one collective of the path: concat of the shards on rank 0, straight into the final
-                # layout (stretch_sharded). Timed as compute + concat per step. A failure here must not cost
-                # the main line: it is reported inside config.concat instead.
-                try:
-                    full = torch.empty((CHANNELS, n_out), dtype=torch.float32, device=device) if rank == 0 else None
-                    k2 = max(2, min(5, args.steps))
-                    stretch_sharded(compute, CHANNELS, nwin, wout, dst=0, full=full)
-                    barrier()
-                    tc = time.perf_counter()
-                    for _ in range(k2):
-                        stretch_sharded(compute, CHANNELS, nwin, wout, dst=0, full=full)
-                    barrier()
-                    dtc = time.perf_counter() - tc
-                    dtc = max_over_ranks(dtc)
-                    concat = {
-                        "steps": k2,
-                        "ms_per_step_with_concat": round(dtc / k2 * 1e3, 4),
-                        "value_with_concat": round(float(n_out) * CHANNELS * k2 / dtc / 1e6, 1),
+            err = f"{type(ex).__name__}: {ex}"[:300]
+        if not all_ranks_ok(err is None):
+            legs[name] = {"error": err or "set-up failed on another rank; leg skipped on all ranks"}
+            note(f"{name}: skipped ({legs[name]['error']})")
+            return
+        try:
+            with torch.cuda.stream(stream):
+                legs[name] = body(state)
+        except Exception as ex:  # noqa: BLE001
+            # past the agreement point: the other ranks may be inside a barrier this rank will never reach. No further
+            # collective is entered here; the watchdog of the ranks left behind ends the job non-zero.
+            legs[name] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            broken[0] = True
+        note(f"{name}: {legs.get(name)}")
+
+    def timed(fn, k, warm=3):
+        for _ in range(warm):
+            fn()
+        barrier()
+        t = time.perf_counter()
+        for _ in range(k):
+            fn()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t) / k
+
+    if world > 1 and not args.no_extras:
+        timer.start()
+        ks = max(args.steps, 20)
+
+        # (1) the fixed job on ONE GPU, in this run: every rank runs the whole job on its own GPU
+        def ref_setup():
+            return torch.empty((CHANNELS, n_out), dtype=torch.float32, device=device)
+
+        def ref_body(full_f):
+            one_f = shard_plan(CHANNELS, nwin, 1)
+            t_1 = timed(lambda: [compute(s, out=full_f[s.ch_first:s.ch_first + s.ch_count]) for s in one_f], ks)
+            t_n = dt / args.steps
+            return {"workload": "the fixed job on every rank's own GPU alone (max over ranks), same run",
+                    "steps": ks, "ms_per_step_1gpu": round(t_1 * 1e3, 4),
+                    "value_1gpu_Msamples_s": round(float(n_out) * CHANNELS / t_1 / 1e6, 1),
+                    "efficiency_vs_1gpu": round(t_1 / (world * t_n), 4)}
+
+        leg("ref_1gpu", ref_setup, ref_body)
+
+        # (2) weak scaling: ONE stereo job of N x L samples per channel, per-GPU work that of N = 1
+        def weak_setup():
+            xw = synth_on_device(torch, device, CHANNELS, L_IN * world)
+            n_out_w = eng.output_len(L_IN * world)
+            plan_w = shard_plan(CHANNELS, n_out_w // wout, world)
+            mine_w = [s for s in plan_w if s.rank == rank]
+            bufs_w = {s: torch.empty((s.ch_count, s.win_count * wout), dtype=torch.float32, device=device) for s in mine_w}
+            return xw, n_out_w, plan_w, mine_w, bufs_w, engine_compute(eng, xw)
+
+        def weak_body(st):
+            xw, n_out_w, plan_w, mine_w, bufs_w, comp_w = st
+            t_w = timed(lambda: [comp_w(s, out=bufs_w[s]) for s in mine_w], ks)
+            return {"scaling": "weak",
+                    "workload": f"one stereo job of L={L_IN * world}/ch ({world} x {L_IN}) cut over {world} rank(s)",
+                    "steps": ks, "ms_per_step": round(t_w * 1e3, 4),
+                    "value_Msamples_s": round(float(n_out_w) * CHANNELS / t_w / 1e6, 1),
+                    "hops_per_rank": sum(s.ch_count * s.win_count for s in mine_w) * eng.params.hops_per_window,
+                    "plan": [(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan_w]}
+
+        leg("weak", weak_setup, weak_body)
+
+        # (3) BASELINE configs[4] (C5: 8 channels, window 65536, factor 32, L = 5 292 000 per channel) cut over the
+        # ranks by the same shard_plan (8 ranks: one channel per GPU, no halo). Not the metric's config.
+        C5 = dict(window=65536, factor=32.0, channels=8, length=5_292_000)
+
+        def c5_setup():
+            eng5 = rocoder_amd.Engine(window_len=C5["window"], factor=C5["factor"], pitch_multiple=1,
+                                      sample_rate=SAMPLE_RATE, channels=C5["channels"], seed=SEED, device=dev_index)
+            x5 = synth_on_device(torch, device, C5["channels"], C5["length"])
+            wout5 = eng5.params.window_out_len
+            n_out5 = eng5.output_len(C5["length"])
+            plan5 = shard_plan(C5["channels"], n_out5 // wout5, world)
+            mine5 = [s for s in plan5 if s.rank == rank]
+            bufs5 = {s: torch.empty((s.ch_count, s.win_count * wout5), dtype=torch.float32, device=device) for s in mine5}
+            return eng5, x5, n_out5, plan5, mine5, bufs5, engine_compute(eng5, x5)
+
+        def c5_body(st):
+            eng5, x5, n_out5, plan5, mine5, bufs5, comp5 = st
+            k5 = max(3, min(10, args.steps))
+            t5 = timed(lambda: [comp5(s, out=bufs5[s]) for s in mine5], k5)
+            r = {"workload": "BASELINE configs[4]: 8 ch, window=65536, factor=32, L=5292000/ch, one job cut by shard_plan",
+                 "steps": k5, "ms_per_step": round(t5 * 1e3, 4),
+                 "value_Msamples_s": round(float(n_out5) * C5["channels"] / t5 / 1e6, 1),
+                 "plan": [(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan5]}
+            eng5.close()
+            return r
+
+        leg("c5_sharded", c5_setup, c5_body)
+
+        # (4) the one collective of the path: concat of the shards on rank 0, straight into the final layout
+        # (stretch_sharded). Timed as compute + concat per step.
+        if rehearsal:
+            legs["concat"] = {"skipped": "rehearsal: gloo has no device-to-device send/recv"}
+            if os.environ.get("ROCODER_BENCH_REHEARSAL") == "hang":
+                del legs["concat"]
+                time.sleep(1e6)
+        else:
+            def concat_setup():
+                return torch.empty((CHANNELS, n_out), dtype=torch.float32, device=device) if rank == 0 else None
+
+            def concat_body(full):
+                k2 = max(2, min(5, args.steps))
+                tc = timed(lambda: stretch_sharded(compute, CHANNELS, nwin, wout, dst=0, full=full), k2, warm=1)
+                return {"steps": k2, "ms_per_step_with_concat": round(tc * 1e3, 4),
+                        "value_with_concat": round(float(n_out) * CHANNELS / tc / 1e6, 1),
                         "bytes_moved_to_rank0": int((n_out * CHANNELS - (my_samples if rank == 0 else 0)) * 4),
                         "how": "grouped RCCL send/recv of each shard into its view of the final [channels, n_out] "
-                               "tensor on rank 0 (root-inbound-bound); no pad, no staging copy",
-                    }
-                    del full
-                except Exception as ex:  # noqa: BLE001
-                    concat = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+                               "tensor on rank 0 (root-inbound-bound); no pad, no staging copy"}
+
+            leg("concat", concat_setup, concat_body)
     emit()
+    if broken[0]:
+        os._exit(4)  # a leg failed past its agreement point: no further collective, the main line is out
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     timer.cancel()
+    return 0
+
+
+def e2e_host(eng, x, torch):
+    """PCIe-inclusive C2 (host buffers in and out; never `value`). Filled in below."""
+    xh = x.cpu().numpy()
+    t_e = time.perf_counter()
+    yh = eng.stretch_host(xh)
+    r = {"pageable_fresh_Msamples_s": round(yh.size / (time.perf_counter() - t_e) / 1e6, 1)}
+    return r
+
+
+def other_configs(torch, device, dev_index, stream, x, threading):
+    """The other single-GPU BASELINE configs, timed the same way (pre-heated, median of the engine's per-launch
+    event times) so that the driver's own run carries them: C3 (pitch 3) and C5 (8 ch, window 65536, f = 32)."""
+    import rocoder_amd
+
+    other = {}
+    try:
+        with torch.cuda.stream(stream):
+            def timed_config(xx, **kw):
+                e2 = rocoder_amd.Engine(sample_rate=SAMPLE_RATE, channels=xx.shape[0], seed=SEED, device=dev_index, **kw)
+                o2 = torch.empty((xx.shape[0], e2.output_len(xx.shape[1])), dtype=torch.float32, device=device)
+                e2.stretch_tensor(xx, out=o2)
+                clk2, stop2 = [], threading.Event()
+
+                def samp():
+                    while not stop2.is_set():
+                        try:
+                            clk2.append(float(torch.cuda.clock_rate(dev_index)))
+                        except Exception:  # noqa: BLE001
+                            return
+                        time.sleep(0.05)
+
+                t2 = threading.Thread(target=samp, daemon=True)
+                t2.start()
+                th = time.perf_counter()
+                while time.perf_counter() - th < 0.7:
+                    for _ in range(4):
+                        e2.stretch_tensor(xx, out=o2)
+                    stream.synchronize()
+                stop2.set()
+                t2.join(timeout=2.0)
+                for _ in range(40):
+                    e2.stretch_tensor(xx, out=o2)
+                stream.synchronize()
+                ms2 = statistics.median(e2.kernel_times(10))
+                _, hops2, _ = e2.last_kernel_stats()
+                nwin = kw["window_len"]
+                r2 = {"kernel_ms": round(ms2, 4), "hops": int(hops2),
+                      "out_Msamples_s": round(o2.numel() / ms2 / 1e3, 1),
+                      "frac_hbm_read": round(hops2 * 4.0 * nwin / ms2 / 1e6 / HBM_PEAK_GBS, 4),
+                      "sclk_mhz_under_load": round(statistics.median(clk2), 1) if clk2 else None}
+                e2.close()
+                del o2
+                return r2
+
+            other["C3_pitch3"] = timed_config(x, window_len=WINDOW, factor=FACTOR, pitch_multiple=3)
+            x5 = synth_on_device(torch, device, 8, 5_292_000)
+            other["C5_8ch_window65536_f32"] = timed_config(x5, window_len=65536, factor=32.0)
+            del x5
+    except Exception as ex:  # noqa: BLE001
+        other["error"] = f"{type(ex).__name__}: {ex}"[:300]
+    return other
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -62,7 +62,7 @@ def shard_view(full, s: Shard, window_out_len: int):
 
 
 def stretch_sharded(compute: Callable[..., "object"], channels: int, total_windows: int,
-                    window_out_len: int, group=None, dst: Optional[int] = 0, full=None):
+                    window_out_len: int, group=None, dst: Optional[int] = 0, full=None, stage_all: bool = False):
     """Run this rank's shards with `compute(shard, out=None) -> tensor[ch_count, win_count*window_out_len]`
     and concatenate: returns the full [channels, total_windows*window_out_len] tensor on rank `dst`
     (every rank when dst is None), else None.
@@ -74,7 +74,9 @@ def stretch_sharded(compute: Callable[..., "object"], channels: int, total_windo
     result). No padding to the longest segment, no staging list, no block-by-block re-copy.
     `full` may be passed in (reused across calls); it must be contiguous.
     `dst` is a rank OF `group` (0 .. group size - 1), like the `rank` fields of the shard plan - not a global rank;
-    with a sub-group, translate a global rank with `dist.get_group_rank(group, global_rank)` first."""
+    with a sub-group, translate a global rank with `dist.get_group_rank(group, global_rank)` first.
+    `stage_all` (diagnostic, the twin of rc_multi_set_staging): the root's OWN shards are computed into separate
+    buffers and travel as messages too (a grouped send to itself), so a single rank walks the whole send / recv code."""
     import torch
     import torch.distributed as dist
 
@@ -83,6 +85,7 @@ def stretch_sharded(compute: Callable[..., "object"], channels: int, total_windo
     assert dst is None or 0 <= dst < world, f"dst={dst} is not a rank of the group (size {world})"
     plan = shard_plan(channels, total_windows, world)
     holds_full = dst is None or rank == dst
+    stage_all = stage_all and dst is not None
     width = total_windows * window_out_len
     outs = {}
     device = None
@@ -91,7 +94,7 @@ def stretch_sharded(compute: Callable[..., "object"], channels: int, total_windo
     for s in plan:
         if s.rank != rank:
             continue
-        if holds_full and full is not None:
+        if holds_full and full is not None and not stage_all:
             outs[s] = compute(s, out=shard_view(full, s, window_out_len))
         else:
             outs[s] = compute(s)
@@ -101,8 +104,9 @@ def stretch_sharded(compute: Callable[..., "object"], channels: int, total_windo
                   if dist.get_backend(group) == "nccl" else torch.device("cpu"))
     if holds_full and full is None:
         full = torch.empty((channels, width), dtype=torch.float32, device=device)
-        for s, o in outs.items():  # first call without a caller buffer: one placement copy
-            shard_view(full, s, window_out_len).copy_(o)
+        if not stage_all:
+            for s, o in outs.items():  # first call without a caller buffer: one placement copy
+                shard_view(full, s, window_out_len).copy_(o)
     if holds_full:
         assert full.is_contiguous() and tuple(full.shape) == (channels, width)
     if dst is None:
@@ -114,13 +118,13 @@ def stretch_sharded(compute: Callable[..., "object"], channels: int, total_windo
         return full
     ops = []
     for s in plan:
-        if s.rank == dst:
+        if s.rank == dst and not stage_all:
             continue
         peer_dst = dist.get_global_rank(group, dst) if group is not None else dst
         peer_src = dist.get_global_rank(group, s.rank) if group is not None else s.rank
         if rank == dst:
             ops.append(dist.P2POp(dist.irecv, shard_view(full, s, window_out_len), peer_src, group))
-        elif rank == s.rank:
+        if rank == s.rank:
             o = outs[s]
             ops.append(dist.P2POp(dist.isend, o if o.is_contiguous() else o.contiguous(), peer_dst, group))
     if ops:
@@ -128,7 +132,14 @@ def stretch_sharded(compute: Callable[..., "object"], channels: int, total_windo
             for w in dist.batch_isend_irecv(ops):  # one grouped RCCL launch
                 w.wait()
         else:
-            for w in [op.op(op.tensor, op.peer, group=op.group) for op in ops]:
+            # gloo (CPU tests) has no message to oneself: a stage_all root pairs its own sends and receives, which
+            # were appended in the same plan order, as plain copies
+            me = dist.get_rank()
+            own_recv = [op.tensor for op in ops if op.peer == me and op.op is dist.irecv]
+            own_send = [op.tensor for op in ops if op.peer == me and op.op is dist.isend]
+            for dst_t, src_t in zip(own_recv, own_send):
+                dst_t.copy_(src_t)
+            for w in [op.op(op.tensor, op.peer, group=op.group) for op in ops if op.peer != me]:
                 w.wait()
     return full if rank == dst else None
 

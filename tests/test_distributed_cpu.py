@@ -69,6 +69,11 @@ def _worker(rank, world, port, x, full_ref, N, f, p, wout, nwin, dst, q):
             assert out2 is buf and torch.equal(out2, out)
         else:
             assert stretch_sharded(compute, x.shape[0], nwin, wout, dst=dst) is None
+        if dst is not None:
+            # stage_all: the root's own shards travel as messages to itself too (what the one-GPU RCCL test walks)
+            buf3 = torch.full((x.shape[0], nwin * wout), float("nan")) if rank == dst else None
+            out3 = stretch_sharded(compute, x.shape[0], nwin, wout, dst=dst, full=buf3, stage_all=True)
+            assert (out3 is buf3 and torch.equal(out3, out)) if rank == dst else out3 is None
         if dst is None or rank == dst:
             q.put((rank, np.array_equal(out.numpy(), full_ref)))
         else:

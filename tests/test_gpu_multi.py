@@ -131,3 +131,27 @@ def test_multi_device_from_plain_c(tmp_path):
                            timeout=300)
         assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
         assert r.stdout.startswith("OK"), r.stdout
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_walks_the_sharded_concat():
+    """the RCCL branch of rocoder_amd.distributed (communicator creation, broadcast into shard
+    views, the grouped send / recv launch) executes on hardware, bit-exact against the single-engine tensor. One rank:
+    RCCL refuses two ranks on one device, and the box has one."""
+    import json
+    import socket
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank.py")], env=env,
+                       capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["backend"] == "nccl" and res["world"] == 1 and res["all_reduce"] == 3.5
+    for k in ("broadcast_all", "root_only", "grouped_send_recv_to_self"):
+        assert res[k] is True and res[k + "_into_caller_buffer"] is True, res
