@@ -492,6 +492,7 @@ def worker(args, say):
         if world == 1:
             extras["e2e_pcie"] = e2e_host(eng, x, torch)
             extras["other_configs"] = other_configs(torch, device, dev_index, stream, x, threading)
+            extras["shard_sizes"] = shard_sizes(torch, device, stream, eng, x, wout, nwin)
 
     res = None
     if rank == 0:
@@ -603,6 +604,8 @@ def worker(args, say):
             best = extras["e2e_pcie"].get("pinned_Msamples_s") or extras["e2e_pcie"].get("pageable_reused_Msamples_s")
             if best:
                 res["config"]["e2e_pcie_Msamples_s"] = best
+        if "shard_sizes" in extras:
+            res["config"]["shard_sizes_on_one_gpu"] = extras["shard_sizes"]
         if "other_configs" in extras:  # not the metric's config: BASELINE configs[2..4] on this one GPU
             res["config"]["other_configs"] = extras["other_configs"]
         if world == 1 and not args.no_cpu_baseline:
@@ -779,12 +782,86 @@ def worker(args, say):
 
 
 def e2e_host(eng, x, torch):
-    """PCIe-inclusive C2 (host buffers in and out; never `value`). Filled in below."""
+    """PCIe-inclusive C2 (host arrays in and out through rc_engine_stretch_host; never `value`): input
+    upload, compute and output download as one pipelined call. Three forms of the same job, median of 3 calls each:
+      pinned           rows from rc_host_alloc on both sides (DMA straight from / into the caller's memory)
+      pageable_reused  ordinary numpy arrays, the output array allocated once and reused (its pages exist)
+      pageable_fresh   a new output array per call (np.empty inside the call: every page is faulted in on the way)"""
+    import numpy as np
+
+    import rocoder_amd
+
     xh = x.cpu().numpy()
-    t_e = time.perf_counter()
-    yh = eng.stretch_host(xh)
-    r = {"pageable_fresh_Msamples_s": round(yh.size / (time.perf_counter() - t_e) / 1e6, 1)}
+    n_out = eng.output_len(xh.shape[1])
+    total = float(n_out) * xh.shape[0]
+    r = {"what": "rc_engine_stretch_host on the C2 job, host arrays in and out, wall time of the blocking call",
+         "pcie_bound_Msamples_s_at_54GBs": round(54e9 / 4 / 1e6, 0)}
+
+    def med(fn, reps=3):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return statistics.median(ts)
+
+    try:
+        xp = rocoder_amd.pinned_empty(xh.shape)
+        xp[:] = xh
+        yp = rocoder_amd.pinned_empty((xh.shape[0], n_out))
+        t = med(lambda: eng.stretch_host(xp, out=yp))
+        r["pinned_Msamples_s"] = round(total / t / 1e6, 1)
+        r["pinned_ms"] = round(t * 1e3, 2)
+        del xp, yp
+    except Exception as ex:  # noqa: BLE001
+        r["pinned_error"] = f"{type(ex).__name__}: {ex}"[:200]
+    try:
+        yh = np.empty((xh.shape[0], n_out), np.float32)
+        t = med(lambda: eng.stretch_host(xh, out=yh))
+        r["pageable_reused_Msamples_s"] = round(total / t / 1e6, 1)
+        del yh
+        t = med(lambda: eng.stretch_host(xh), reps=2)
+        r["pageable_fresh_Msamples_s"] = round(total / t / 1e6, 1)
+    except Exception as ex:  # noqa: BLE001
+        r["pageable_error"] = f"{type(ex).__name__}: {ex}"[:200]
     return r
+
+
+def shard_sizes(torch, device, stream, eng, x, wout, nwin):
+    """What ONE rank of an N-way cut of the fixed job costs, measured on this one GPU (N = 2, 4, 8: rank 0's shard
+    of shard_plan, the launch bench.py --gpus N times on every rank). It is the per-rank compute of the strong-scaling
+    run - run length quantisation, the recomputed hop, launch overhead at 6 456 hops per rank - and says nothing about
+    a node's fabric (the data path has no collective). NOT a multi-GPU measurement."""
+    from rocoder_amd.distributed import engine_compute, shard_plan
+
+    out = {}
+    try:
+        comp = engine_compute(eng, x)
+        with torch.cuda.stream(stream):
+            for n in (2, 4, 8):
+                mine = [s for s in shard_plan(CHANNELS, nwin, n) if s.rank == 0]
+                bufs = {s: torch.empty((s.ch_count, s.win_count * wout), dtype=torch.float32, device=device) for s in mine}
+                for _ in range(50):
+                    for s in mine:
+                        comp(s, out=bufs[s])
+                stream.synchronize()
+                k = 200
+                t = time.perf_counter()
+                for _ in range(k):
+                    for s in mine:
+                        comp(s, out=bufs[s])
+                stream.synchronize()
+                wall = (time.perf_counter() - t) / k
+                kms = statistics.median(eng.kernel_times(32))
+                hops = sum(s.ch_count * s.win_count for s in mine) * eng.params.hops_per_window
+                out[f"1_of_{n}"] = {"hops": hops, "kernel_ms": round(kms, 4), "step_wall_ms": round(wall * 1e3, 4),
+                                    "frac_hbm_read": round(hops * 4.0 * WINDOW / kms / 1e6 / HBM_PEAK_GBS, 4),
+                                    "job_Msamples_s_if_all_ranks_alike": round(float(nwin) * wout * CHANNELS / wall / 1e6, 1)}
+                del bufs
+    except Exception as ex:  # noqa: BLE001
+        out["error"] = f"{type(ex).__name__}: {ex}"[:300]
+    return out
 
 
 def other_configs(torch, device, dev_index, stream, x, threading):
@@ -838,7 +915,56 @@ def other_configs(torch, device, dev_index, stream, x, threading):
             del x5
     except Exception as ex:  # noqa: BLE001
         other["error"] = f"{type(ex).__name__}: {ex}"[:300]
+    try:
+        other["C4_host_kernel_x2"] = c4_config(torch, device, dev_index, stream, x)
+    except Exception as ex:  # noqa: BLE001
+        other["C4_host_kernel_x2"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
     return other
+
+
+def c4_config(torch, device, dev_index, stream, x):
+    """BASELINE configs[3] at its own size: the C2 job with the README's x2.0 apply() (README.md:121-128) as a compiled
+    C-ABI host kernel, two kernel threads. Input and output resident in HBM as for `value`; every hop's N-bin spectrum
+    crosses PCIe both ways (2 x 6.77 GB) and passes through the host callback: PCIe- and callback-bound, not on the
+    roofline line."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    import rocoder_amd
+
+    tmp = tempfile.mkdtemp(prefix="rocoder_c4_")
+    try:
+        src, so = os.path.join(tmp, "gain2.c"), os.path.join(tmp, "libgain2.so")
+        with open(src, "w") as fh:
+            fh.write("#include <stddef.h>\n#include <stdint.h>\n"
+                     "int apply(uint64_t t, const float *in, float *out, size_t n, void *u) {\n"
+                     "    (void)t; (void)u;\n    for (size_t i = 0; i < 2 * n; ++i) out[i] = in[i] * 2.0f;\n    return 0;\n}\n")
+        subprocess.run(["gcc", "-O3", "-shared", "-fPIC", "-o", so, src], check=True, timeout=120)
+        k = rocoder_amd.load_kernel_library(so)
+        with torch.cuda.stream(stream):
+            e4 = rocoder_amd.Engine(window_len=WINDOW, factor=FACTOR, pitch_multiple=PITCH, sample_rate=SAMPLE_RATE,
+                                    channels=x.shape[0], seed=SEED, device=dev_index, kernel=k, kernel_threads=2)
+            o4 = torch.empty((x.shape[0], e4.output_len(x.shape[1])), dtype=torch.float32, device=device)
+            e4.stretch_tensor(x[:, :1_000_000].contiguous(), out=o4)  # pinned sets, scratch
+            stream.synchronize()
+            ts = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                e4.stretch_tensor(x, out=o4)
+                stream.synchronize()
+                e4.synchronize()
+                ts.append(time.perf_counter() - t0)
+            _, hops4, _ = e4.last_kernel_stats()
+            r = {"ms": round(min(ts) * 1e3, 1), "hops": int(hops4), "kernel_threads": 2,
+                 "out_Msamples_s": round(o4.numel() / min(ts) / 1e6, 1),
+                 "spectrum_GB_each_way": round(hops4 * WINDOW * 8 / 1e9, 2),
+                 "note": "device-resident in / out; spectra over PCIe both ways + host apply(); best of 2 calls"}
+            e4.close()
+            del o4
+        return r
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -24,8 +24,8 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 4 /* 3: + rc_shard_plan / rc_multi_*; 4: + rc_engine_next_window_view, rc_multi_set_staging,
-                          * rc_calib_valu (struct layouts unchanged since 2) */
+#define RC_ABI_VERSION 5 /* 3: + rc_shard_plan / rc_multi_*; 4: + rc_engine_next_window_view, rc_multi_set_staging,
+                          * rc_calib_valu; 5: + rc_host_alloc / rc_host_free (struct layouts unchanged since 2) */
 
 /* status codes */
 #define RC_OK 0
@@ -156,8 +156,17 @@ size_t rc_engine_channel_bound(const rc_engine *e);
 /* Whole-job stretch of `channels` host arrays of `in_len` samples: what main.rs:133-155 +
  * StretcherProcessor::start (src/stretcher_processor.rs:56-71) + AudioBus::into_audio
  * (src/audio.rs:152-172) produce. out[c] must hold rc_offline_output_len() samples. */
+/* Upload, compute and download run as a pipeline over window chunks (the download of chunk i under the kernel of
+ * chunk i + 1 and the upload of chunk i + 2). Rows that came from rc_host_alloc (or that the caller registered with
+ * hipHostRegister) are the DMA's source / target themselves; pageable rows are staged through pinned slots by up to
+ * eight copy threads. Blocking: out[c] is complete on return. */
 int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, float *const *out,
                            size_t out_cap, size_t *out_len);
+/* Page-locked host memory for the host-form calls (the `Vec<f32>` a Rust host would otherwise hand over, src/main.rs:
+ * 148, src/audio.rs:152-172): rows allocated here cross PCIe without a staging copy. rc_host_free(NULL) is a no-op.
+ * RC_ENODEVICE without a GPU, RC_ENOMEM when the pages cannot be locked. */
+int rc_host_alloc(size_t bytes, void **out);
+int rc_host_free(void *p);
 /* Same job on DEVICE-resident buffers (channel c at base + c*stride, strides in floats).
  * `hip_stream` is a hipStream_t (NULL = the engine's own stream); the call is asynchronous
  * on that stream unless a user kernel is configured. The engine's scratch (tail copy, seam stash,

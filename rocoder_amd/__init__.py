@@ -3,6 +3,6 @@ overlap-add stretch path. The compute lives in librocoder_hip.so (hand-written H
 include/rocoder_hip.h); this package is the host-side mirror of the reference interface."""
 from .stretcher import (AudioBus, AudioSpec, Engine, MultiEngine, ReFFT, RocoderError, Stretcher,  # noqa: F401
                         StretcherProcessor, derive_params, load_kernel_library,
-                        offline_output_len, stretch)
+                        offline_output_len, pinned_empty, stretch)
 
 __version__ = "0.1.0"

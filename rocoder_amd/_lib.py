@@ -100,6 +100,8 @@ SYMBOLS = {
     "rc_engine_channel_bound": (_sz, [_eng]),
     "rc_engine_stretch_host": (C.c_int, [_eng, C.POINTER(_fp), _sz, C.POINTER(_fp), _sz,
                                          C.POINTER(_sz)]),
+    "rc_host_alloc": (C.c_int, [_sz, C.POINTER(C.c_void_p)]),
+    "rc_host_free": (C.c_int, [C.c_void_p]),
     "rc_engine_stretch_device": (C.c_int, [_eng, C.c_void_p, _sz, _sz, C.c_void_p, _sz, _sz,
                                            C.POINTER(_sz), C.c_void_p]),
     "rc_engine_stretch_device_range": (C.c_int, [_eng, C.c_void_p, _sz, _sz, C.c_uint32, C.c_uint32,

@@ -26,6 +26,8 @@
 #include <mutex>
 #include <vector>
 
+#include <sys/mman.h>  // madvise(MADV_POPULATE_WRITE): host_pipeline
+
 namespace {
 // Worker threads that are always joined: if a later std::thread constructor throws (std::system_error), the ones
 // already started must not be destroyed joinable (std::terminate) - the C ABI's catch (...) turns the failure into
@@ -150,6 +152,15 @@ uint64_t offline_windows(const rc_params &p, size_t in_len) {
     return kd / p.hops_per_window + 1;
 }
 
+// samples [lo, hi) of the input that the hops of windows [w0, w1) read, incl. the recomputed hop before them
+void input_span(const rc_params &p, uint64_t w0, uint64_t w1, size_t in_len, size_t *lo, size_t *hi) {
+    const uint64_t h0 = w0 * p.hops_per_window, h1 = w1 * p.hops_per_window;
+    const uint64_t first = h0 > 0 ? h0 - 1 : 0;
+    const uint64_t a = first * p.sample_step_len, b = (h1 - 1) * p.sample_step_len + p.window_len;
+    *lo = (size_t)std::min<uint64_t>(a, in_len);
+    *hi = (size_t)std::min<uint64_t>(b, in_len);
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -268,6 +279,7 @@ struct rc_engine {
         hipStream_t st[kWorkers] = {};
         hipEvent_t ev_start = nullptr;
         int max_workers = kWorkers;  // (rc_multi: the listed devices' engines copy at the same time and share the host's cores)
+        std::vector<hipEvent_t> ev_chunk;  // host_pipeline: one "chunk computed" event per window chunk (pooled)
     } hp;
 };
 
@@ -1383,6 +1395,7 @@ void rc_engine_destroy(rc_engine *e) {
         if (e->hp.st[i]) (void)hipStreamDestroy(e->hp.st[i]);
     }
     if (e->hp.ev_start) (void)hipEventDestroy(e->hp.ev_start);
+    for (hipEvent_t ev : e->hp.ev_chunk) (void)hipEventDestroy(ev);
     if (e->ev_last) (void)hipEventDestroy(e->ev_last);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     if (e->h_err) (void)hipHostFree(e->h_err);
@@ -1676,6 +1689,252 @@ int host_copy(rc_engine *e, bool to_device, float *const *host, float *dev, size
     // (H2D: every worker synchronised its stream, so whatever is launched on e->stream next sees the data)
     return RC_OK;
 }
+
+// ---- host-buffer jobs as a pipeline (round 5) --------------------------------------------------------------------
+// A piece = channels [ch_first, ch_first + ch_count) x windows [w0, w1) of the job, with its own device regions: d_in
+// holds samples [in_lo, in_lo + span) of each of its channels (row stride span), d_out its n_sh output samples per
+// channel. The piece is cut into window chunks of about one staging slot of output per channel; per chunk:
+//   upload the part of the input span the chunk reads beyond what earlier chunks brought  (copy workers)
+//   run_hops of the chunk on the engine's stream, an event behind it                      (calling thread)
+//   download the chunk, one task per channel and slot-sized part                          (copy workers)
+// so that the download of chunk i runs under the kernel of chunk i + 1 and the upload of chunk i + 2 (PCIe is full
+// duplex). Rows the caller allocated with rc_host_alloc (or registered with hipHostRegister) are the DMA's source /
+// target themselves; pageable rows are staged through the workers' pinned slots, the destination pages of a download
+// populated (MADV_POPULATE_WRITE) while its DMA is in flight.
+struct HostPiece {
+    uint32_t ch_first, ch_count;
+    uint64_t w0, w1;
+    float *d_in;
+    size_t in_lo, span;
+    float *d_out;
+    size_t n_sh;
+};
+
+bool row_is_pinned(const float *p, size_t n) {
+    if (!p || n == 0) return true;
+    for (const float *q : {p, p + (n - 1)}) {
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (at.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+#ifndef RC_POPULATE_MODE
+#define RC_POPULATE_MODE 3  // bit 0: MADV_POPULATE_WRITE, bit 1: MADV_HUGEPAGE first (A/B: tests/dev/e2e_host.py, profiles/README.md)
+#endif
+// A download into pageable memory the caller has never touched (a fresh output array) takes a page fault per 4 KiB
+// while it is copied. Ahead of the copy, while the DMA of the piece is in flight: ask for huge pages on the part of the
+// destination that can take them and have the kernel populate the range in one call.
+void populate_pages(void *p, size_t bytes) {
+#if defined(__linux__) && defined(MADV_POPULATE_WRITE)
+    const uintptr_t lo = (uintptr_t)p, hi = lo + bytes;
+    if (RC_POPULATE_MODE & 2) {
+        const uintptr_t huge = (uintptr_t)2 << 20, a = (lo + huge - 1) & ~(huge - 1), b = hi & ~(huge - 1);
+        if (b > a) (void)madvise((void *)a, b - a, MADV_HUGEPAGE);
+    }
+    if (RC_POPULATE_MODE & 1) {
+        const uintptr_t page = 4096, a = (lo + page - 1) & ~(page - 1), b = hi & ~(page - 1);
+        if (b > a) (void)madvise((void *)a, b - a, MADV_POPULATE_WRITE);  // (older kernels: EINVAL, the memcpy faults them in)
+    }
+#else
+    (void)p;
+    (void)bytes;
+#endif
+}
+
+int host_pipeline(rc_engine *e, const std::vector<HostPiece> &pieces, const float *const *in_rows, size_t in_len,
+                  float *const *out_rows) {
+    using HP = rc_engine::HostPipe;
+    const rc_params &par = e->par;
+    const uint64_t wout = par.window_out_len;
+    const uint32_t hpw = par.hops_per_window;
+    const size_t slot_floats = HP::kSlotBytes / sizeof(float);
+    struct Task {
+        bool up;
+        uint32_t c;       // absolute channel
+        size_t host_off;  // offset into the caller's row
+        float *dev;
+        size_t cnt;
+        int gate;         // download: the chunk whose event it waits for
+    };
+    struct Chunk {
+        size_t piece;
+        uint64_t w0, w1;
+        size_t need_up;  // upload tasks [0, need_up) must be on the device before the chunk is launched
+    };
+    std::vector<Task> ups, downs_of_chunk_flat;
+    std::vector<Chunk> chunks;
+    std::vector<std::pair<size_t, size_t>> down_range;  // per chunk: [first, last) into downs_of_chunk_flat
+    std::vector<size_t> up_until;                        // per chunk: its upload tasks end here (exclusive) in `ups`
+    bool in_pinned = true, out_pinned = true;
+    for (size_t pi = 0; pi < pieces.size(); ++pi) {
+        const HostPiece &pc = pieces[pi];
+        if (pc.w1 <= pc.w0 || pc.ch_count == 0) continue;
+        for (uint32_t c = 0; c < pc.ch_count; ++c) {
+            in_pinned = in_pinned && row_is_pinned(in_rows[pc.ch_first + c] + pc.in_lo, pc.span);
+            out_pinned = out_pinned && row_is_pinned(out_rows[pc.ch_first + c] + (size_t)(pc.w0 * wout), pc.n_sh);
+        }
+        const uint64_t wc = std::max<uint64_t>(1, slot_floats / std::max<uint64_t>(1, wout));
+        size_t brought = 0;  // samples of the piece's span already scheduled for upload
+        for (uint64_t w = pc.w0; w < pc.w1; w += wc) {
+            const uint64_t we = std::min<uint64_t>(pc.w1, w + wc);
+            size_t lo, hi;
+            input_span(par, w, we, in_len, &lo, &hi);
+            const size_t upto = we == pc.w1 ? pc.span : std::min(pc.span, hi > pc.in_lo ? hi - pc.in_lo : 0);
+            for (size_t off = brought; off < upto; off += slot_floats) {
+                const size_t cnt = std::min(slot_floats, upto - off);
+                for (uint32_t c = 0; c < pc.ch_count; ++c)
+                    ups.push_back(Task{true, pc.ch_first + c, pc.in_lo + off, pc.d_in + (size_t)c * pc.span + off, cnt, -1});
+            }
+            brought = std::max(brought, upto);
+            chunks.push_back(Chunk{pi, w, we, ups.size()});
+            up_until.push_back(ups.size());
+            const size_t first = downs_of_chunk_flat.size();
+            const size_t o0 = (size_t)((w - pc.w0) * wout), o1 = (size_t)((we - pc.w0) * wout);
+            for (uint32_t c = 0; c < pc.ch_count; ++c)
+                for (size_t off = o0; off < o1; off += slot_floats)
+                    downs_of_chunk_flat.push_back(Task{false, pc.ch_first + c, (size_t)(pc.w0 * wout) + off,
+                                                       pc.d_out + (size_t)c * pc.n_sh + off, std::min(slot_floats, o1 - off),
+                                                       (int)(chunks.size() - 1)});
+            down_range.emplace_back(first, downs_of_chunk_flat.size());
+        }
+    }
+    if (chunks.empty()) return RC_OK;
+    // one list in an order that is a valid schedule: uploads of chunk k + 1 in front of the downloads of chunk k
+    std::vector<Task> tasks;
+    std::vector<long> up_index;  // per task: its index among the uploads, or -1
+    tasks.reserve(ups.size() + downs_of_chunk_flat.size());
+    {
+        size_t u = 0;
+        auto push_ups = [&](size_t until) {
+            for (; u < until; ++u) {
+                tasks.push_back(ups[u]);
+                up_index.push_back((long)u);
+            }
+        };
+        push_ups(up_until[0]);
+        for (size_t k = 0; k < chunks.size(); ++k) {
+            if (k + 1 < chunks.size()) push_ups(up_until[k + 1]);
+            for (size_t d = down_range[k].first; d < down_range[k].second; ++d) {
+                tasks.push_back(downs_of_chunk_flat[d]);
+                up_index.push_back(-1);
+            }
+        }
+    }
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    int workers = std::max(1, std::min(e->hp.max_workers, (int)HP::kWorkers));
+    workers = (int)std::min<size_t>((size_t)std::min<unsigned>((unsigned)workers, hw), tasks.size());
+    if (in_pinned && out_pinned) workers = std::min(workers, 4);  // nothing to memcpy: the workers only keep the DMA queues fed
+    for (int w = 0; w < workers; ++w) {
+        if (!e->hp.slot[w] && !(in_pinned && out_pinned))
+            RC_HIP(hipHostMalloc(&e->hp.slot[w], HP::kSlotBytes, hipHostMallocDefault));
+        if (!e->hp.st[w]) RC_HIP(hipStreamCreateWithFlags(&e->hp.st[w], hipStreamNonBlocking));
+    }
+    while (e->hp.ev_chunk.size() < chunks.size()) {
+        hipEvent_t ev = nullptr;
+        RC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e->hp.ev_chunk.push_back(ev);
+    }
+    if (!e->hp.ev_start) RC_HIP(hipEventCreateWithFlags(&e->hp.ev_start, hipEventDisableTiming));
+    // the uploads overwrite d_in: behind whatever the engine's stream still holds
+    RC_HIP(hipEventRecord(e->hp.ev_start, e->stream));
+    for (int w = 0; w < workers; ++w) RC_HIP(hipStreamWaitEvent(e->hp.st[w], e->hp.ev_start, 0));
+
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> up_done(ups.size(), 0);
+    size_t up_prefix = 0;  // uploads [0, up_prefix) are on the device
+    long launched = 0;     // chunks [0, launched) have their event recorded
+    bool failed = false;
+    std::atomic<size_t> next{0};
+    auto fail_all = [&] {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            failed = true;
+        }
+        cv.notify_all();
+    };
+    auto work = [&](int w) {
+        if (hipSetDevice(e->device) != hipSuccess) return fail_all();
+        float *slot = (float *)e->hp.slot[w];
+        hipStream_t st = e->hp.st[w];
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= tasks.size()) return;
+            const Task &t = tasks[i];
+            const size_t bytes = t.cnt * sizeof(float);
+            if (t.up) {
+                const float *h = in_rows[t.c] + t.host_off;
+                const void *src = h;
+                if (!in_pinned) {
+                    std::memcpy(slot, h, bytes);
+                    src = slot;
+                }
+                if (hipMemcpyAsync(t.dev, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess)
+                    return fail_all();
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    up_done[(size_t)up_index[i]] = 1;
+                    while (up_prefix < up_done.size() && up_done[up_prefix]) ++up_prefix;
+                }
+                cv.notify_all();
+            } else {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return failed || launched > t.gate; });
+                    if (failed) return;
+                }
+                float *h = out_rows[t.c] + t.host_off;
+                if (hipStreamWaitEvent(st, e->hp.ev_chunk[(size_t)t.gate], 0) != hipSuccess ||
+                    hipMemcpyAsync(out_pinned ? (void *)h : (void *)slot, t.dev, bytes, hipMemcpyDeviceToHost, st) != hipSuccess)
+                    return fail_all();
+                if (!out_pinned) populate_pages(h, bytes);  // page faults of a fresh output array, under the DMA
+                if (hipStreamSynchronize(st) != hipSuccess) return fail_all();
+                if (!out_pinned) std::memcpy(h, slot, bytes);
+            }
+        }
+    };
+    JoinedThreads th;
+    int started = 0;
+    for (int w = 0; w < workers; ++w) started += th.start(work, w) ? 1 : 0;
+    int rc = RC_OK;
+    if (started == 0) {
+        fail_all();
+        rc = fail(RC_ENOMEM, "host pipeline: no copy worker thread could be started");
+    }
+    for (size_t k = 0; k < chunks.size() && rc == RC_OK; ++k) {
+        const Chunk &ck = chunks[k];
+        const HostPiece &pc = pieces[ck.piece];
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return failed || up_prefix >= ck.need_up; });
+            if (failed) break;
+        }
+        rc = run_hops(e, pc.d_in, pc.span, (int64_t)pc.in_lo, (int64_t)in_len - (int64_t)pc.in_lo, pc.ch_first, pc.ch_count,
+                      (int64_t)(ck.w0 * hpw), (int64_t)((ck.w1 - ck.w0) * hpw), pc.d_out, pc.n_sh, (int64_t)(pc.w0 * wout),
+                      e->stream, k == 0);
+        if (rc == RC_OK && hipEventRecord(e->hp.ev_chunk[k], e->stream) != hipSuccess) rc = fail(RC_EHIP, "hipEventRecord failed");
+        if (rc != RC_OK) {
+            fail_all();
+            break;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            launched = (long)k + 1;
+        }
+        cv.notify_all();
+    }
+    th.join();
+    if (rc != RC_OK) return rc;
+    if (failed) return fail(RC_EHIP, "host pipeline: a copy failed: %s", hipGetErrorString(hipGetLastError()));
+    RC_HIP(hipStreamSynchronize(e->stream));
+    return check_device_error(e);
+}
 }  // namespace
 
 int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, float *const *out,
@@ -1691,6 +1950,13 @@ int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, 
     const size_t in_stride = std::max<size_t>(in_len, 1);
     if ((rc = e->d_in.reserve((size_t)C * in_stride * sizeof(float)))) return rc;
     if ((rc = e->d_out.reserve((size_t)C * std::max<size_t>(n_out, 1) * sizeof(float)))) return rc;
+    if (!e->cfg.kernel) {  // upload, compute and download overlapped chunk by chunk (host_pipeline)
+        std::vector<HostPiece> piece{HostPiece{0, C, 0, total_win, (float *)e->d_in.p, 0, in_len, (float *)e->d_out.p, n_out}};
+        if ((rc = host_pipeline(e, piece, in, in_len, out))) return rc;
+        if (out_len) *out_len = n_out;
+        return RC_OK;
+    }
+    // a host frequency kernel has its own three-stage pipeline over the spectra: whole input up, whole output down
     if ((rc = host_copy(e, true, const_cast<float *const *>(in), (float *)e->d_in.p, in_stride, in_len, C))) return rc;
     rc = rc_engine_stretch_device_range(e, (const float *)e->d_in.p, in_stride, in_len, 0, C, 0, total_win,
                                         (float *)e->d_out.p, n_out, n_out, e->stream);
@@ -1702,6 +1968,36 @@ int rc_engine_stretch_host(rc_engine *e, const float *const *in, size_t in_len, 
     return RC_OK;
 } catch (...) {
     return rc_catch();
+}
+
+int rc_host_alloc(size_t bytes, void **out) try {
+    if (!out) return fail(RC_EINVAL, "null argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(RC_ENODEVICE, "no HIP device: page-locked memory is allocated through the HIP runtime");
+    }
+    void *p = nullptr;
+    const hipError_t err = hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocPortable);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RC_ENOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(err));
+    }
+    *out = p;
+    return RC_OK;
+} catch (...) {
+    return rc_catch();
+}
+
+int rc_host_free(void *p) {
+    if (!p) return RC_OK;
+    const hipError_t err = hipHostFree(p);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RC_EINVAL, "hipHostFree: %s (not a pointer from rc_host_alloc?)", hipGetErrorString(err));
+    }
+    return RC_OK;
 }
 
 int rc_engine_synchronize(rc_engine *e) {
@@ -1955,14 +2251,6 @@ int for_each_device(rc_multi *m, const std::function<int(size_t)> &fn) {
             return fail(m->workers.res[i].rc, "device %d (list index %zu): %s", m->dev[i], i, m->workers.res[i].msg.c_str());
     return RC_OK;
 }
-// samples [lo, hi) of the input that the hops of windows [w0, w1) read, incl. the recomputed hop before them
-void input_span(const rc_params &p, uint64_t w0, uint64_t w1, size_t in_len, size_t *lo, size_t *hi) {
-    const uint64_t h0 = w0 * p.hops_per_window, h1 = w1 * p.hops_per_window;
-    const uint64_t first = h0 > 0 ? h0 - 1 : 0;
-    const uint64_t a = first * p.sample_step_len, b = (h1 - 1) * p.sample_step_len + p.window_len;
-    *lo = (size_t)std::min<uint64_t>(a, in_len);
-    *hi = (size_t)std::min<uint64_t>(b, in_len);
-}
 // the calling thread's current device is put back on every way out of an rc_multi_* call
 struct DeviceRestore {
     int prev = -1;
@@ -2081,12 +2369,7 @@ int multi_share(rc_multi *m, size_t i, const std::vector<rc_shard> &plan, bool h
         if (int rc = m->d_out[i].reserve(std::max<size_t>(1, need_out) * sizeof(float))) return rc;
     }
     size_t off_in = 0, off_out = 0;
-    struct Deliver {  // host form: the shards go out after all pieces are computed (one pass of the copy workers each)
-        const rc_shard *sh;
-        float *from;
-        size_t n;
-    };
-    std::vector<Deliver> deliver;
+    std::vector<HostPiece> host_pieces;  // host form: all pieces of the share go through ONE upload / compute / download pipeline
     for (const rc_shard &sh : plan) {
         if (sh.device_index != i || sh.win_count == 0) continue;
         const size_t n_sh = (size_t)(sh.win_count * wout);
@@ -2104,36 +2387,24 @@ int multi_share(rc_multi *m, size_t i, const std::vector<rc_shard> &plan, bool h
         float *li = (float *)m->d_in[i].p + off_in, *lo_ = (float *)m->d_out[i].p + off_out;
         off_in += (size_t)sh.ch_count * span;
         off_out += (size_t)sh.ch_count * n_sh;
-        if (span) {
-            if (host) {  // pinned staging slots + copy workers (host_copy), not the runtime's pageable path
-                std::vector<float *> rows(sh.ch_count);
-                for (uint32_t c = 0; c < sh.ch_count; ++c) rows[c] = const_cast<float *>(src_rows[sh.ch_first + c]) + lo;
-                if (int rc = host_copy(e, true, rows.data(), li, span, span, sh.ch_count)) return rc;
-            } else {
-                for (uint32_t c = 0; c < sh.ch_count; ++c)
-                    RC_HIP(hipMemcpyPeerAsync(li + (size_t)c * span, dev, src + (size_t)(sh.ch_first + c) * src_stride + lo,
-                                              root_dev, span * sizeof(float), s));
-            }
+        if (host) {  // pinned staging slots + copy workers, not the runtime's pageable path (host_pipeline)
+            host_pieces.push_back(HostPiece{sh.ch_first, sh.ch_count, sh.win_first, sh.win_first + sh.win_count, li, lo, span, lo_, n_sh});
+            continue;
         }
+        for (uint32_t c = 0; span && c < sh.ch_count; ++c)
+            RC_HIP(hipMemcpyPeerAsync(li + (size_t)c * span, dev, src + (size_t)(sh.ch_first + c) * src_stride + lo,
+                                      root_dev, span * sizeof(float), s));
         // the local buffer holds samples [lo, hi) of each channel: in_origin = lo, and the samples that exist end at
         // in_len (a window running past it is zero-padded by the engine as in the whole job)
         int rc = run_hops(e, li, span, (int64_t)lo, (int64_t)in_len - (int64_t)lo, sh.ch_first, sh.ch_count,
                           (int64_t)(sh.win_first * hpw), (int64_t)(sh.win_count * hpw), lo_, n_sh,
                           (int64_t)(sh.win_first * wout), s, true);
         if (rc) return rc;
-        if (host) {
-            deliver.push_back(Deliver{&sh, lo_, n_sh});
-        } else {
-            for (uint32_t c = 0; c < sh.ch_count; ++c)
-                RC_HIP(hipMemcpyPeerAsync(dst + (size_t)(sh.ch_first + c) * dst_stride + (size_t)(sh.win_first * wout),
-                                          root_dev, lo_ + (size_t)c * n_sh, dev, n_sh * sizeof(float), s));
-        }
+        for (uint32_t c = 0; c < sh.ch_count; ++c)
+            RC_HIP(hipMemcpyPeerAsync(dst + (size_t)(sh.ch_first + c) * dst_stride + (size_t)(sh.win_first * wout),
+                                      root_dev, lo_ + (size_t)c * n_sh, dev, n_sh * sizeof(float), s));
     }
-    for (const Deliver &d : deliver) {
-        std::vector<float *> rows(d.sh->ch_count);
-        for (uint32_t c = 0; c < d.sh->ch_count; ++c) rows[c] = dst_rows[d.sh->ch_first + c] + (size_t)(d.sh->win_first * wout);
-        if (int rc = host_copy(e, false, rows.data(), d.from, d.n, d.n, d.sh->ch_count)) return rc;
-    }
+    if (host) return host_pipeline(e, host_pieces, src_rows, in_len, dst_rows);
     RC_HIP(hipStreamSynchronize(s));
     return check_device_error(e);
 }

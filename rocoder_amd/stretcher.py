@@ -124,6 +124,33 @@ def offline_output_len(in_len: int, **kw) -> int:
     return int(_lib.lib().rc_offline_output_len(C.byref(cfg), in_len))
 
 
+class _PinnedBlock:
+    """Owner of one rc_host_alloc block; numpy arrays made over it keep it alive through their `base` chain."""
+
+    def __init__(self, nbytes: int):
+        self._L = _lib.lib()
+        p = C.c_void_p()
+        check(self._L.rc_host_alloc(nbytes, C.byref(p)), self._L)
+        self.ptr, self.nbytes = p.value, nbytes
+        self.__array_interface__ = {"shape": (max(nbytes, 1),), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        p, self.ptr = getattr(self, "ptr", None), None
+        if p:
+            self._L.rc_host_free(C.c_void_p(p))
+
+
+def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
+    """numpy array in page-locked host memory (rc_host_alloc): rows handed to `Engine.stretch_host` /
+    `MultiEngine.stretch_host` from here cross PCIe by DMA without a staging copy. The block is freed when the last
+    array (or view) over it is garbage-collected."""
+    shape = tuple(int(v) for v in np.atleast_1d(shape))
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape))
+    blk = _PinnedBlock(n * dt.itemsize)
+    return np.asarray(blk)[:n * dt.itemsize].view(dt).reshape(shape)
+
+
 class Engine:
     """Thin RAII wrapper of rc_engine (all channels of one job)."""
 
@@ -192,19 +219,28 @@ class Engine:
     def output_len(self, in_len: int) -> int:
         return int(self._L.rc_offline_output_len(C.byref(self._cfg), in_len))
 
-    def stretch_host(self, channels_in) -> np.ndarray:
-        x = np.ascontiguousarray(np.atleast_2d(channels_in), dtype=np.float32)
+    def stretch_host(self, channels_in, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Host arrays in, host arrays out (rc_engine_stretch_host). `out` (float32 [channels, >= output_len], rows
+        contiguous) is filled and returned when given - reuse it across calls, and allocate both sides with
+        `pinned_empty` to let the DMA engines read / write them directly (no staging copy)."""
+        x = np.atleast_2d(channels_in)
+        if x.dtype != np.float32 or x.strides[-1] != 4:
+            x = np.ascontiguousarray(x, dtype=np.float32)
         if x.shape[0] != self.channels:
             raise ValueError("channel count mismatch")
         n_out = self.output_len(x.shape[1])
-        out = np.empty((self.channels, n_out), np.float32)
+        if out is None:
+            out = np.empty((self.channels, n_out), np.float32)
+        elif (out.dtype != np.float32 or out.ndim != 2 or out.shape[0] != self.channels or out.shape[1] < n_out
+              or out.strides[1] != 4):
+            raise ValueError(f"out must be float32 [{self.channels}, >= {n_out}] with contiguous rows")
         fp = C.POINTER(C.c_float)
         ins = (fp * self.channels)(*[_fp(x[c]) for c in range(self.channels)])
         outs = (fp * self.channels)(*[_fp(out[c]) for c in range(self.channels)])
         got = C.c_size_t(0)
-        self._check(self._L.rc_engine_stretch_host(self._h, ins, x.shape[1], outs, n_out, C.byref(got)))
+        self._check(self._L.rc_engine_stretch_host(self._h, ins, x.shape[1], outs, out.shape[1], C.byref(got)))
         assert got.value == n_out
-        return out
+        return out[:, :n_out]
 
     def stretch_device_ptr(self, d_in: int, in_stride: int, in_len: int, d_out: int, out_stride: int,
                            out_cap: int, stream: int = 0) -> int:
@@ -310,18 +346,24 @@ class MultiEngine:
     def output_len(self, in_len: int) -> int:
         return int(self._L.rc_offline_output_len(C.byref(self._cfg), in_len))
 
-    def stretch_host(self, x: np.ndarray) -> np.ndarray:
-        x = np.ascontiguousarray(np.atleast_2d(x), dtype=np.float32)
+    def stretch_host(self, x: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
+        x = np.atleast_2d(x)
+        if x.dtype != np.float32 or x.strides[-1] != 4:
+            x = np.ascontiguousarray(x, dtype=np.float32)
         assert x.shape[0] == self.channels
         n_out = self.output_len(x.shape[1])
-        out = np.empty((self.channels, n_out), np.float32)
+        if out is None:
+            out = np.empty((self.channels, n_out), np.float32)
+        elif (out.dtype != np.float32 or out.ndim != 2 or out.shape[0] != self.channels or out.shape[1] < n_out
+              or out.strides[1] != 4):
+            raise ValueError(f"out must be float32 [{self.channels}, >= {n_out}] with contiguous rows")
         fp = C.POINTER(C.c_float)
         ins = (fp * self.channels)(*[r.ctypes.data_as(fp) for r in x])
         outs = (fp * self.channels)(*[r.ctypes.data_as(fp) for r in out])
         got = C.c_size_t(0)
-        self._check(self._L.rc_multi_stretch_host(self._h, ins, x.shape[1], outs, n_out, C.byref(got)))
+        self._check(self._L.rc_multi_stretch_host(self._h, ins, x.shape[1], outs, out.shape[1], C.byref(got)))
         assert got.value == n_out
-        return out
+        return out[:, :n_out]
 
     def set_staging(self, force: bool):
         """Diagnostic (rc_multi_set_staging): shares on the root's own device take the copy path of a remote one."""

@@ -78,6 +78,26 @@ static void offline(uint32_t N, float f, int p, uint32_t ch, size_t L, rc_freq_k
         CHECK(got == n_out);
     }
     CHECK(rc_engine_stretch_host(e, in.data(), L, out.data(), n_out ? n_out - 1 : 0, &got) == RC_ECAPACITY || n_out == 0);
+    {  // rows from rc_host_alloc: the pipeline's direct-DMA form (no staging slot), then one side pinned, one pageable
+        std::vector<void *> blocks;
+        std::vector<const float *> pin;
+        std::vector<float *> pout;
+        for (uint32_t i = 0; i < ch; ++i) {
+            void *a = nullptr, *b = nullptr;
+            CHECK(rc_host_alloc(std::max<size_t>(L, 1) * sizeof(float), &a) == RC_OK && a);
+            CHECK(rc_host_alloc(std::max<size_t>(n_out, 1) * sizeof(float), &b) == RC_OK && b);
+            if (L) memcpy(a, x[i].data(), L * sizeof(float));
+            blocks.push_back(a);
+            blocks.push_back(b);
+            pin.push_back((const float *)a);
+            pout.push_back((float *)b);
+        }
+        CHECK(rc_engine_stretch_host(e, pin.data(), L, pout.data(), n_out, &got) == RC_OK && got == n_out);
+        CHECK(rc_engine_stretch_host(e, pin.data(), L, out.data(), n_out, &got) == RC_OK && got == n_out);
+        CHECK(rc_engine_stretch_host(e, in.data(), L, pout.data(), n_out, &got) == RC_OK && got == n_out);
+        for (void *b : blocks) CHECK(rc_host_free(b) == RC_OK);
+        CHECK(rc_host_free(nullptr) == RC_OK);
+    }
     CHECK(rc_engine_synchronize(e) == RC_OK);
     float ms[8];
     size_t nms = 0;
@@ -186,6 +206,8 @@ int main() {
     offline(3000, 2.0f, 1, 1, 20000, nullptr, 0);
     offline(2048, 2.0f, -2, 2, 30000, nullptr, 0);
     offline(256, 0.3f, 1, 1, 5000, nullptr, 0);
+    offline(16384, 8.0f, 1, 2, 1500000, nullptr, 0);  // 12 M output samples per channel: three chunks in the host pipeline
+    offline(4096, 0.3f, 1, 2, 9000000, nullptr, 0);   // more input than output: the uploads dominate
     offline(1024, 2.0f, 1, 1, 0, nullptr, 0);    // empty input
     offline(1024, 2.0f, 1, 1, 1023, nullptr, 0); // shorter than a window
     // host frequency kernel: the three-set pinned pipeline, 1 and 4 kernel threads, chunks smaller than the job
@@ -206,6 +228,7 @@ int main() {
     }
     // several devices in one process: the persistent workers, host and device form, in place and staged
     multi({0, 0, 0}, 16384, 8.0f, 1, 2, 300000);
+    multi({0, 1}, 16384, 8.0f, 1, 3, 1500000);  // shards of three chunks each through the host pipeline
     multi({0, 1, 2}, 16384, 8.0f, 3, 3, 200000);
     multi({2, 0, 0, 1, 3, 3, 1, 2}, 1024, 2.0f, 2, 1, 50000);
     multi({1}, 65536, 32.0f, 1, 8, 150000);

@@ -63,11 +63,19 @@ hipError_t hipFree(void *p) {
     free(p);
     return hipSuccess;
 }
+static std::map<const void *, size_t> g_host;  // page-locked blocks (hipPointerGetAttributes: hipMemoryTypeHost)
 hipError_t hipHostMalloc(void **p, size_t n, unsigned) {
     *p = calloc(1, n ? n : 1);
-    return *p ? hipSuccess : hipErrorOutOfMemory;
+    if (!*p) return hipErrorOutOfMemory;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_host[*p] = n ? n : 1;
+    return hipSuccess;
 }
 hipError_t hipHostFree(void *p) {
+    if (p) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_host.erase(p)) return hipErrorInvalidValue;
+    }
     free(p);
     return hipSuccess;
 }
@@ -85,6 +93,16 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p) {
             a->type = hipMemoryTypeDevice;
             a->device = it->second.second;
             a->devicePointer = const_cast<void *>(p);
+            return hipSuccess;
+        }
+    }
+    auto ih = g_host.upper_bound(p);
+    if (ih != g_host.begin()) {
+        --ih;
+        if ((const char *)p < (const char *)ih->first + ih->second) {
+            memset(a, 0, sizeof *a);
+            a->type = hipMemoryTypeHost;
+            a->hostPointer = const_cast<void *>(p);
             return hipSuccess;
         }
     }

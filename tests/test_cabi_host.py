@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/rocoder_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
-    assert L.rc_abi_version() == 4
+    assert L.rc_abi_version() == 5
 
 
 def test_product_library_reads_no_diagnostic_variable_and_hook_build_loads():

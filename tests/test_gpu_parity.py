@@ -1315,3 +1315,128 @@ def test_4096_8192_wave_local_kernels_every_sample_and_ranges(N, p):
     while not st.is_done():
         wins.append(st.next_window())
     assert_parity(got1, np.concatenate(wins), f"{N} table window p={p}")
+
+
+@pytest.mark.parametrize("N,f,p,ch,L", [
+    (16384, 8.0, 1, 2, 3_000_000),    # 24 M output samples per channel: six chunks of the pipeline
+    (16384, 8.0, 3, 2, 1_600_000),
+    (65536, 32.0, 1, 3, 700_000),     # 22 M per channel through big4_kernel
+    (4096, 0.3, 1, 2, 30_000_000),    # more input than output: the uploads are the long side
+    (2048, 2.0, -2, 2, 4_000_000),    # negative pitch: windows of (S - 1) |p| samples
+    (3000, 4.0, 1, 1, 2_000_000),     # chirp-z window length
+    (1024, 8.0, 1, 1, 700_000),
+])
+def test_host_pipeline_equals_the_device_path_bit_for_bit(N, f, p, ch, L):
+    """rc_engine_stretch_host runs upload / compute / download as a pipeline over window chunks (round 5): pageable rows,
+    rows from rc_host_alloc on either or both sides, a reused output array wider than needed - all the same bits as the
+    one-launch job on device-resident tensors. (Parity of that job with the oracle: the tests above.)"""
+    import torch
+
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, L) for c in range(ch)])
+    with ra.Engine(window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=0x5EED) as e:
+        ref = e.stretch_tensor(torch.from_numpy(x).cuda()).cpu().numpy()
+        n_out = ref.shape[1]
+        assert n_out == e.output_len(L)
+        assert np.array_equal(e.stretch_host(x), ref)
+        xp = ra.pinned_empty(x.shape)
+        xp[:] = x
+        yp = ra.pinned_empty((ch, n_out + 5))
+        yp[:] = np.nan
+        got = e.stretch_host(xp, out=yp)
+        assert got.base is not None and np.array_equal(got, ref) and np.all(np.isnan(yp[:, n_out:]))
+        yh = np.full((ch, n_out), np.nan, np.float32)
+        assert np.array_equal(e.stretch_host(xp, out=yh), ref)      # pinned in, pageable out
+        yp[:] = np.nan
+        assert np.array_equal(e.stretch_host(x, out=yp), ref)       # pageable in, pinned out
+        with pytest.raises(ValueError):
+            e.stretch_host(x, out=np.empty((ch, n_out - 1), np.float32))
+    if N in (16384, 65536):
+        with ra.MultiEngine([0, 0, 0], window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=0x5EED) as m:
+            assert np.array_equal(m.stretch_host(x), ref)
+            yp[:] = np.nan
+            assert np.array_equal(m.stretch_host(xp, out=yp), ref)
+
+
+def test_host_pipeline_with_a_host_kernel_keeps_the_call_order():
+    """With a host frequency kernel rc_engine_stretch_host keeps the whole-input / whole-output order around the
+    spectrum pipeline (a stateful apply() sees every hop once, in the reference's order): same result as before."""
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, 300_000) for c in range(2)])
+    calls = []
+
+    def k(t, spec):
+        calls.append(len(spec))
+        return spec * np.float32(2.0)
+
+    with ra.Engine(window_len=4096, factor=4.0, channels=2, seed=5, kernel=k) as e:
+        got = e.stretch_host(x)
+        n_calls = len(calls)
+        yp = ra.pinned_empty(got.shape)
+        assert np.array_equal(e.stretch_host(x, out=yp), got) and len(calls) == 2 * n_calls
+    with ra.Engine(window_len=4096, factor=4.0, channels=2, seed=5) as e:
+        plain = e.stretch_host(x)
+    assert_parity(got, 2.0 * plain, "x2 kernel through the host form")
+
+
+def test_baseline_c4_at_its_own_size(tmp_path):
+    """BASELINE configs[3] at the size the metric names: stereo, window 16384, factor 8, L = 26 460 000 per channel
+    (51 652 hops, 6.7 GB of spectrum each way through the compiled x2.0 apply()): F_C4 == 2 F_C2 on every sample
+    (the size-independent property; oracle parity of this path: test_baseline_c4_window_16384_user_kernel)."""
+    import torch
+
+    ra = _engine_mod()
+    k = _compiled_gain2(tmp_path)
+    N, f, seed, L = 16384, 8.0, 0x5EED, 26_460_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    t = torch.arange(L, device="cuda", dtype=torch.float32) / 44100.0
+    x = torch.stack([0.5 * torch.sin(2 * torch.pi * 220.0 * (c + 1) * t) +
+                     0.05 * (torch.rand(L, device="cuda", generator=g) * 2 - 1) for c in range(2)]).contiguous()
+    del t
+    with ra.Engine(window_len=N, factor=f, channels=2, seed=seed) as e2:
+        f2 = e2.stretch_tensor(x)
+        torch.cuda.synchronize()
+        e2.synchronize()
+    with ra.Engine(window_len=N, factor=f, channels=2, seed=seed, kernel=k, kernel_time_ms=77, kernel_threads=2) as e4:
+        f4 = e4.stretch_tensor(x)
+        torch.cuda.synchronize()
+        e4.synchronize()
+        _, hops, _ = e4.last_kernel_stats()
+    assert f4.shape == f2.shape == (2, 211_566_592)
+    assert hops == 2 * (f4.shape[1] // (N // 2)) == 51_652
+    num = den = 0.0
+    worst = 0.0
+    blk = 1 << 24
+    for c in range(2):
+        for o in range(0, f2.shape[1], blk):
+            a, b = f4[c, o:o + blk].double(), f2[c, o:o + blk].double()
+            d = a - 2.0 * b
+            num += float(d.pow(2).sum())
+            den += float(b.pow(2).sum())
+            worst = max(worst, float(d.abs().max()))
+    rel = (num / den) ** 0.5
+    assert rel <= 2e-6 and worst <= 1e-4, (rel, worst)
+
+
+@pytest.mark.parametrize("N,L,f,p,ch", [
+    (16384, 150_000, 2.0, 16, 2),     # step 256, 32 hops per window
+    (4096, 40_000, 1.0, 16, 1),
+    (65536, 200_000, 1.0, 127, 1),    # i8::MAX: step 258, 254 hops per window, 8.3 M samples needed per window
+    (16384, 120_000, 0.5, 127, 2),    # step 129
+    (16384, 300_000, 512.0, -128, 2),  # i8::MIN: S = 128, windows of 127 * 128 samples, step 2048
+    (2048, 60_000, 64.0, -128, 1),    # step == window_len
+    (4096, 100_000, 254.0, -127, 1),
+])
+def test_pitch_multiple_i8_corners_match_oracle(N, L, f, p, ch):
+    """`-p` is an i8 in the reference (src/main.rs `pitch_multiple: i8`; src/stretcher.rs:40 only forbids 0): the far
+    ends of its range, with windows and factors that keep sample_step_len >= 1."""
+    ra = _engine_mod()
+    par = ra.derive_params(window_len=N, factor=f, pitch_multiple=p)
+    assert par.sample_step_len >= 1
+    x = np.stack([onp.synth_input(c, L) for c in range(ch)])
+    got = ra.stretch(x, window_len=N, factor=f, pitch_multiple=p, seed=0x5EED)
+    ref = oc.stretch_offline(x, N, f, 1.0, p, seed=0x5EED)
+    assert got.shape == ref.shape
+    for c in range(ch):
+        assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}", reg=4.0e-6)

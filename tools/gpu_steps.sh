@@ -1,0 +1,16 @@
+#!/bin/bash
+# Runs GPU steps one after the other on the gpurun box; a step that times out or is killed ends the sequence (no
+# further GPU step is started after a hang), an ordinary failure (a red test) does not.
+#   usage: source tools/gpu_steps.sh; step <seconds> <name> <command...>
+mkdir -p gpurun_out
+STOP=0
+step() {
+    local limit=$1 name=$2; shift 2
+    if [ "$STOP" != 0 ]; then echo "[skip $name: an earlier step was killed]"; return; fi
+    echo "=== $name"
+    timeout -k 10 "$limit" "$@" > "gpurun_out/$name.log" 2>&1
+    local rc=$?
+    echo "[$name rc=$rc]"
+    tail -n 6 "gpurun_out/$name.log"
+    if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then STOP=1; fi
+}
