@@ -82,46 +82,56 @@ def synth_on_device(torch, device, channels, length):
     return torch.stack(rows).contiguous()
 
 
-def pmc_traffic(kernel_id):
-    """HBM-side bytes per hop-kernel launch from the committed rocprofv3 PMC passes of this same
-    command (profiles/, separate --pmc runs: FETCH_SIZE, WRITE_SIZE in KiB). Per
-    MI355X_MICROARCH.md §HBM, FETCH_SIZE on gfx950 tallies 128-B read requests at 64 B, so the read
-    side is doubled; WRITE_SIZE is exact. Only a summary that names the kernels this library holds
-    (`kernel_id:` line) is quoted: counters of an older kernel say nothing about this one.
-    Returns (bytes, source) or (None, reason)."""
+def pmc_counters(family_id, section=None):
+    """Mean counter values per launch from the committed rocprofv3 PMC passes (profiles/r*_pmc_summary.txt, separate
+    --pmc runs) of the kernel family `family_id` ("hop4=<hash>", "big4=<hash>": rc_kernel_id() hashes each family's
+    sources at build time). Only a summary headed by exactly this id is quoted: counters of another build of the
+    kernel say nothing about this one. `section`: the "## ..." block of a summary that holds several kernels.
+    Returns (dict, relative path) or (None, reason)."""
     import glob
     import re
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")), reverse=True):
         txt = open(path).read()
         kid = re.search(r"^#?\s*kernel_id:\s*(\S+)", txt, re.M)
-        if not kid or kid.group(1) != kernel_id:
+        if not kid or kid.group(1) != family_id:
             continue
-        f = re.search(r"FETCH_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt)
-        w = re.search(r"WRITE_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt)
-        if f and w:
-            return (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0, os.path.relpath(path, ROOT)
-    return None, f"no profiles/r*_pmc_summary.txt for kernel_id {kernel_id}"
-
-
-def pmc_valu(kernel_id):
-    """VALU occupancy and instruction count of the hop kernel from the same committed PMC summary (or None):
-    SQ_ACTIVE_INST_VALU counts quad-cycles summed over all waves; 1024 SIMDs x the launch's busy cycles is what the
-    chip offers. GRBM_GUI_ACTIVE is summed over the 8 XCDs."""
-    import glob
-    import re
-
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")), reverse=True):
-        txt = open(path).read()
-        kid = re.search(r"^#?\s*kernel_id:\s*(\S+)", txt, re.M)
-        if not kid or kid.group(1) != kernel_id:
-            continue
+        if section is not None:
+            parts = re.split(r"^## ", txt, flags=re.M)
+            txt = next((p for p in parts if p.startswith(section)), "")
         g = {k: float(v) for k, v in re.findall(r"^(\w+)\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt, re.M)}
-        if {"SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU"} <= set(g):
-            simd_cycles = g["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
-            return {"valu_busy": round(4.0 * g["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3),
-                    "valu_insts_per_launch": g["SQ_INSTS_VALU"], "source": os.path.relpath(path, ROOT)}
+        if g:
+            return g, os.path.relpath(path, ROOT)
+    return None, f"no profiles/r*_pmc_summary.txt headed by kernel_id {family_id}"
+
+
+def pmc_traffic(family_id, section=None):
+    """HBM-side bytes per launch: FETCH_SIZE, WRITE_SIZE in KiB. Per MI355X_MICROARCH.md (HBM / rocprofv3),
+    FETCH_SIZE on gfx950 tallies 128-B read requests at 64 B, so the read side is doubled; WRITE_SIZE is exact."""
+    g, src = pmc_counters(family_id, section)
+    if g and "FETCH_SIZE" in g and "WRITE_SIZE" in g:
+        return (2.0 * g["FETCH_SIZE"] + g["WRITE_SIZE"]) * 1024.0, src
+    return None, src if g is None else f"{src}: no FETCH_SIZE / WRITE_SIZE"
+
+
+def pmc_valu(family_id, section=None):
+    """VALU occupancy and instruction count from the same summary (or None): SQ_ACTIVE_INST_VALU counts quad-cycles
+    summed over all waves; 1024 SIMDs x the launch's busy cycles is what the chip offers. GRBM_GUI_ACTIVE is summed
+    over the 8 XCDs."""
+    g, src = pmc_counters(family_id, section)
+    if g and {"SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU"} <= set(g):
+        simd_cycles = g["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+        return {"valu_busy": round(4.0 * g["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3),
+                "valu_insts_per_launch": g["SQ_INSTS_VALU"], "source": src}
     return None
+
+
+def family_id(full_id, family):
+    """'hop4=<hash>' out of rc_kernel_id()'s 'hop4=<hash> big4=<hash> ...'."""
+    import re
+
+    m = re.search(r"\b%s=([0-9a-f]+)" % family, full_id)
+    return f"{family}={m.group(1)}" if m else full_id
 
 
 def cpu_baselines(all_cores=True):
@@ -368,7 +378,8 @@ def worker(args, say):
     from rocoder_amd import _lib
     from rocoder_amd.distributed import engine_compute, shard_plan, stretch_sharded
 
-    kernel_id = _lib.lib().rc_kernel_id().decode()
+    kernel_ids = _lib.lib().rc_kernel_id().decode()
+    kernel_id = family_id(kernel_ids, "hop4")  # the bench kernel's family
     # ONE job for all ranks, the same at every N: same seed, same (replicated, device-generated) input
     eng = rocoder_amd.Engine(window_len=WINDOW, factor=FACTOR, pitch_multiple=PITCH,
                              sample_rate=SAMPLE_RATE, channels=CHANNELS, seed=SEED, device=dev_index)
@@ -491,7 +502,7 @@ def worker(args, say):
             del a, b
         if world == 1:
             extras["e2e_pcie"] = e2e_host(eng, x, torch)
-            extras["other_configs"] = other_configs(torch, device, dev_index, stream, x, threading)
+            extras["other_configs"] = other_configs(torch, device, dev_index, stream, x, threading, kernel_ids)
             extras["shard_sizes"] = shard_sizes(torch, device, stream, eng, x, wout, nwin)
 
     res = None
@@ -592,6 +603,7 @@ def worker(args, say):
                 "hops_per_rank": hops_mine,
                 "output_samples_per_step": n_out * CHANNELS,
                 "x_realtime": round(value * 1e6 / CHANNELS / SAMPLE_RATE, 1),
+                "kernel_ids": kernel_ids,
                 "parallelism": (f"{world} rank(s): one job cut into (channel, hop range) shards by shard_plan "
                                 f"{[(s.rank, s.ch_first, s.ch_count, s.win_first, s.win_count) for s in plan]}, "
                                 "outputs left sharded in HBM, no data-path collective; one kernel launch per shard and "
@@ -864,7 +876,7 @@ def shard_sizes(torch, device, stream, eng, x, wout, nwin):
     return out
 
 
-def other_configs(torch, device, dev_index, stream, x, threading):
+def other_configs(torch, device, dev_index, stream, x, threading, kernel_ids=""):
     """The other single-GPU BASELINE configs, timed the same way (pre-heated, median of the engine's per-launch
     event times) so that the driver's own run carries them: C3 (pitch 3) and C5 (8 ch, window 65536, f = 32)."""
     import rocoder_amd
@@ -911,7 +923,16 @@ def other_configs(torch, device, dev_index, stream, x, threading):
 
             other["C3_pitch3"] = timed_config(x, window_len=WINDOW, factor=FACTOR, pitch_multiple=3)
             x5 = synth_on_device(torch, device, 8, 5_292_000)
-            other["C5_8ch_window65536_f32"] = timed_config(x5, window_len=65536, factor=32.0)
+            c5 = timed_config(x5, window_len=65536, factor=32.0)
+            # HBM traffic / VALU occupancy of big4_kernel<64> from the committed C5 counter passes of THIS kernel build
+            fam = family_id(kernel_ids, "big4")
+            c5["kernel_id"] = fam
+            c5["traffic"], c5["traffic_source"] = pmc_traffic(fam, "R64")
+            pv = pmc_valu(fam, "R64")
+            if pv:
+                c5["valu_busy"] = pv["valu_busy"]
+                c5["valu_insts_per_hop"] = round(pv["valu_insts_per_launch"] / max(1, c5["hops"]), 1)
+            other["C5_8ch_window65536_f32"] = c5
             del x5
     except Exception as ex:  # noqa: BLE001
         other["error"] = f"{type(ex).__name__}: {ex}"[:300]

@@ -476,7 +476,11 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             *slot = got;
         }
         __syncthreads();
-        gr = *reinterpret_cast<volatile unsigned *>(slot);
+        // the ticket is the same for every lane: as a scalar, the run, the channel, the hop counter and the hop's phase
+        // key (two 64-bit multiplies of mix64) live in SGPRs and run on the scalar unit. Read through LDS it was a
+        // VGPR value: the key was computed per lane and its channel word was one of the kernel's spills, reloaded
+        // every hop behind an s_waitcnt vmcnt(0) (tools/isa_stats.py --spills)
+        gr = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile unsigned *>(slot));
         __syncthreads();
         if (gr == 0xFFFFFFFFu) return;  // (more workgroups than runs: cannot happen with the engine's grid)
     }

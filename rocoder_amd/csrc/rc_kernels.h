@@ -140,8 +140,9 @@ struct BigOlaParams {
     uint32_t tail_only;     // 1: compute tails only, store nothing to out
 };
 
-// kernel generation (rc_kernel_id): bump whenever a change to the kernels can move a measurement
-#define RC_KERNEL_ID "hop4+big4/r04a"
+// rc_kernel_id(): "hop4=<hash> big4=<hash> hopw=<hash> generic=<hash> spectrum=<hash>", one hash per kernel family
+// over its sources, generated at build time into $(OBJDIR)/rc_kernel_id.h (tools/kernel_id.py, csrc/Makefile) - a
+// changed kernel can never be quoted next to counters taken with another one
 
 enum HopMode { MODE_FUSED = 0, MODE_FORWARD = 1, MODE_RESYNTH = 2 };
 // values a kernel may leave in *HopParams::err_word

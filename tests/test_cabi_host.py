@@ -300,3 +300,33 @@ def test_integration_md_rust_stub_matches_the_header():
     assert sorted(protos) == _header_functions()
     for name in protos:
         assert fns[name] == protos[name], (name, fns[name], protos[name])
+
+
+def test_kernel_id_is_a_hash_of_the_kernel_sources_and_current_profiles_match_it():
+    """rc_kernel_id() = one hash per kernel family over its sources, the shared headers and the device flags, generated
+    at build time (tools/kernel_id.py): the built library holds the ids of the sources in the tree, the test-hook build
+    the same ones, and every counter summary profiles/CURRENT.json names as current is headed by the id the library
+    holds for that family - a kernel changed after its counters were taken fails here (re-profile, or drop the entry:
+    bench.py then quotes no counters for it)."""
+    import json
+    import re
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    L = _lib.lib()
+    have = dict(re.findall(r"(\w+)=([0-9a-f]+)", L.rc_kernel_id().decode()))
+    assert set(have) == {"hop4", "big4", "hopw", "generic", "spectrum"}, have
+    csrc = os.path.join(ROOT, "rocoder_amd", "csrc")
+    flags = subprocess.run(["make", "-s", "-C", csrc, "print-flags"], capture_output=True, text=True, check=True).stdout
+    want = json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_id.py"), "--json", csrc] +
+                                     flags.split(), capture_output=True, text=True, check=True).stdout)
+    assert have == want, "librocoder_hip.so was built from other kernel sources than the tree holds: run build()"
+    with _lib.hooks_library() as H:
+        assert H.rc_kernel_id() == L.rc_kernel_id()
+    cur = json.load(open(os.path.join(ROOT, "profiles", "CURRENT.json")))
+    for fam, name in cur["pmc_summary"].items():
+        txt = open(os.path.join(ROOT, "profiles", name)).read()
+        m = re.search(r"^#\s*kernel_id:\s*(\S+)", txt, re.M)
+        assert m and m.group(1) == f"{fam}={have[fam]}", (fam, name, m and m.group(1), have[fam])

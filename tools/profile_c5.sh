@@ -26,6 +26,13 @@ for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
             key = "R64 (N=65536)" if "Li64E" in r["Kernel_Name"] or "<64" in r["Kernel_Name"] else "R32 (N=32768)"
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(f"{out}/{tag}_pmc_summary.txt", "w") as g:
+    try:  # the family id of the kernels these counters belong to (rc_kernel_id(): a hash of the big4 sources)
+        import os, re
+        sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
+        from rocoder_amd import _lib
+        g.write("# kernel_id: big4=" + re.search(r"big4=([0-9a-f]+)", _lib.lib().rc_kernel_id().decode()).group(1) + "\n")
+    except Exception as e:  # noqa: BLE001
+        g.write(f"# (no kernel id: {e})\n")
     try:
         import json
         b = json.loads(open(f"{out}/{tag}_bench.json").read())
