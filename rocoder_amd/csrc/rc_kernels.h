@@ -154,6 +154,8 @@ constexpr uint32_t RC_DIAG_SKIP_SEAM_PUBLISH = 1;
 constexpr uint32_t RC_DIAG_PREV_KERNEL = 2;
 // test-hook library only: hop2_kernel's computed-window variant (two workgroups per CU) instead of hop4
 constexpr uint32_t RC_DIAG_HOP2_HANN = 4;
+// test-hook library only: N = 65536 through big4_kernel<64> (round 4's kernel) instead of big5_kernel: A/B partner
+constexpr uint32_t RC_DIAG_BIG4_64 = 8;
 #ifndef RC_TEST_HOOKS
 #define RC_TEST_HOOKS 0
 #endif
@@ -212,6 +214,9 @@ hipError_t launch_big_cr(const BigOlaParams &p, hipStream_t s);
 // runs * n_channels * N/2 floats. One workgroup walks one run and
 // recomputes the hop before it for its tail.
 hipError_t launch_big4(int log2n, const HopParams &p, hipStream_t s);
+// N = 65536 (BASELINE C5): big4_kernel<64>'s arithmetic with wave-local E2 / E3 exchanges (rc_big5.hip); same HopParams
+hipError_t launch_big5(const HopParams &p, hipStream_t s);
+size_t big5_lds_bytes();
 // floats of per-workgroup tail scratch (HopParams::ybuf) big4_kernel needs per run for this window length: 0 when
 // the carried tail y_{k-1}[H..] lives in registers (the default build, both lengths)
 size_t big4_tail_scratch_floats(int log2n);

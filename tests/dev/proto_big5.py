@@ -6,15 +6,16 @@ T = 512 threads x R = 64 complex points, eight waves, one LDS buffer cut into ei
                      j = P6..10, round g = P5
   F3  stages 11..14  same wave, lane = x | a << 4: thread tau = member(k, a) | x << 5 holds residues tau, RES - tau,
                      tau + 512, RES - 512 - tau (16 registers = P11..14 each): E2 never leaves the wave
-  I1 stages 0..3 on the same sets; I2 stages 4..8: same wave, lane = l4 | a << 4 (l4 = P'0..3, class bits = P'10..14),
+  I1 stages 0..3 on the same sets; I2 stages 4..9: same wave, lane = l4 | a << 4 (l4 = P'0..3, class bits = P'10..14),
                      registers j = P'4..8, group = P'9: E3 never leaves the wave
-  I3  stages 9..14   thread = tid = P'0..8, registers P'9..14, half = P'14                        (as big4)
+  I3  stages 10..14  thread = tid = P'0..8, registers P'10..14 per round P'9 (stage 14 in the epilogue)
 Residue classes (low five residue bits, closed under negation so that the (j, M - j) pair stage stays in a thread):
   class k = {k, k + 16, 32 - k, 16 - k} (k = 1..7), class 0 = {0, 16, 24, 8}; all members of a class have k's parity,
   so in E4 the waves of even classes hold the P'14 = 0 half (round 0) and the odd ones the other (round 1).
 Cross-wave exchanges: E1 round 0 writer-major (a wave stores into its OWN region, everybody reads everywhere), round 1
-reader-major (stores go everywhere, a wave reads its OWN region): three barriers, none at the entry. E4 round 0: an
-even wave stores its 64 registers into its own and its odd neighbour's region (entry barrier), round 1 reader-major.
+reader-major (stores go everywhere, a wave reads its OWN region): three barriers, none at the entry. E4 the same, its
+round being the I2 group P'9 (I2 runs stages 4..9, I3 stages 10..13 on P'10..13; a first design with I2 = 4..8 made the
+round P'14 = the class parity: half of the waves would have stored 64 registers per round and kept them live too long).
 Checks: who gets what, and the bank conflicts of every wave instruction (ds_write_b64: 16-lane groups over 16 slots,
 ds_read_b64: 32-lane groups over 32 slots, as measured in round 3)."""
 T, R, b, m, RES = 512, 64, 6, 15, 2048
@@ -205,41 +206,39 @@ def run():
                 for j in range(32):
                     want = l4 | j << 4 | grp << 9 | brev(member(k, a), 5) << 10
                     assert I2[t][32 * grp + j] == want, ("I2", t, grp, j, I2[t][32 * grp + j], want)
-    # ---- E4. round 0: the waves of even classes store all 64 registers (P'14 = 0) into their own and their odd
-    # neighbour's region: index l4 | reg << 4 | a << 10 (reg = P'4..9); round 1: odd classes, reader-major:
-    # region = P'6..8, index P'0..5 | (P'9..13) << 6
+    # ---- E4. I2 runs stages 4..9 (4..8 on each group of 32, then stage 9 across the groups), so the round of E4 is
+    # the group g = P'9 and I3 = stages 10..13 on the registers P'10..13 with P'9 and P'14 looking on (14 in the epilogue).
+    # round 0 writer-major: own region, index l4 | j << 4 | a << 9; round 1 reader-major: region P'6..8, index
+    # P'0..5 | (P'10..14) << 6. No barrier at the entry (own region last read by the wave's own E3): three barriers.
     I3 = {t: [None] * R for t in range(T)}
     for g in range(2):
         for k, wv in enumerate(waves):
-            if (k & 1) != g:
-                continue
-            for reg in range(64):
+            for j in range(32):
                 ad, vals = [], []
                 for t in wv:
                     lane = t & 63
                     l4, a = lane & 15, lane >> 4
-                    P = I2[t][reg]
-                    assert (P >> 14) == g
+                    P = I2[t][32 * g + j]
+                    assert ((P >> 9) & 1) == g
                     if g == 0:
-                        ad.append(REGION * k + (l4 | reg << 4 | a << 10))
+                        ad.append(REGION * k + (l4 | j << 4 | a << 9))
                     else:
-                        ad.append(REGION * ((P >> 6) & 7) + ((P & 63) | ((P >> 9) & 31) << 6))
+                        ad.append(REGION * ((P >> 6) & 7) + ((P & 63) | (P >> 10) << 6))
                     vals.append(P)
                 lds.access(f"E4.r{g}.st", "w", ad, vals)
         for w, wv in enumerate(waves):
-            for q in range(32):
+            for r5 in range(32):
                 ad = []
                 for t in wv:
-                    P = t | q << 9 | g << 14
+                    P = t | g << 9 | r5 << 10
                     if g == 0:
-                        k, a = CLASS_OF[brev((P >> 10) & 31, 5)]
-                        assert k % 2 == 0
-                        ad.append(REGION * k + ((P & 15) | ((P >> 4) & 63) << 4 | a << 10))
+                        k, a = CLASS_OF[brev(r5, 5)]
+                        ad.append(REGION * k + (t | a << 9))
                     else:
-                        ad.append(REGION * w + ((P & 63) | q << 6))
+                        ad.append(REGION * w + ((t & 63) | r5 << 6))
                 got = lds.access(f"E4.r{g}.ld", "r", ad)
                 for t, x in zip(wv, got):
-                    I3[t][q + 32 * g] = x
+                    I3[t][(g | (r5 & 15) << 1) + 32 * (r5 >> 4)] = x   # y[q + 32 h]: q = P'9..13, h = P'14
     for t in range(T):
         for q in range(R):
             assert I3[t][q] == (t | q << 9), ("I3", t, q)

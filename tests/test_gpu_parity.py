@@ -1440,3 +1440,38 @@ def test_pitch_multiple_i8_corners_match_oracle(N, L, f, p, ch):
     assert got.shape == ref.shape
     for c in range(ch):
         assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}", reg=4.0e-6)
+
+
+@pytest.mark.parametrize("ch,L,table_window,p", [(3, 700_000, False, 1), (1, 300_000, True, 1), (2, 500_000, False, 3)])
+def test_big5_agrees_with_big4_at_window_65536(monkeypatch, ch, L, table_window, p):
+    """N = 65536: big5_kernel (round 5: wave-local E2 / E3 exchanges, six barriers per hop) against round 4's
+    big4_kernel<64> (ROCODER_DIAG=8 in the test-hook library). Same butterflies, twiddles and pair stage element for
+    element except the inverse stage 9, whose twiddle now comes from the table instead of four squarings: agreement
+    far inside the oracle gate, on the computed default window, a caller's window and a decimating store."""
+    import torch
+
+    ra = _engine_mod()
+    from rocoder_amd import _lib
+
+    N, f, seed = 65536, 16.0, 0x5EED
+    x = np.stack([onp.synth_input(c, L) for c in range(ch)])
+    xt = torch.from_numpy(x).cuda()
+    kw = dict(window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=seed)
+    if table_window:
+        kw["window"] = (oc.hanning(N).astype(np.float64) ** 1.5).astype(np.float32)
+    with ra.Engine(**kw) as e:
+        new = e.stretch_tensor(xt).clone()
+        torch.cuda.synchronize()
+        e.synchronize()
+    monkeypatch.setenv("ROCODER_DIAG", "8")
+    with _lib.hooks_library(), ra.Engine(**kw) as e:
+        old = e.stretch_tensor(xt).clone()
+        torch.cuda.synchronize()
+        e.synchronize()
+    assert new.shape == old.shape and torch.isfinite(new).all()
+    for c in range(ch):
+        d = new[c].double() - old[c].double()
+        ref_rms = float(old[c].double().pow(2).mean().sqrt())
+        assert ref_rms > 0.01
+        assert float(d.pow(2).mean().sqrt()) <= 1e-6 * ref_rms, (c, float(d.pow(2).mean().sqrt()) / ref_rms)
+        assert float(d.abs().max()) <= 2e-5, c
