@@ -259,13 +259,20 @@ struct WavStreamWriter {
     AudioSpec spec;
     uint64_t frames = 0;
     std::vector<float> row;
-    WavStreamWriter(const std::string &path, const AudioSpec &sp) : spec(sp) {
-        f = fopen(path.c_str(), "wb");
-        if (!f) throw std::runtime_error("cannot create " + path);
+    std::string path, tmp;
+    // The samples go to "<path>.part" and the file takes its name in finish(): a run that fails half way (a device
+    // error, a full disk) leaves no output file with empty size fields behind (the reference writes nothing before the
+    // whole output exists, src/main.rs:197-203)
+    WavStreamWriter(const std::string &path_, const AudioSpec &sp) : spec(sp), path(path_), tmp(path_ + ".part") {
+        f = fopen(tmp.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot create " + tmp);
         write_wav_header(f, spec, 0);
     }
     ~WavStreamWriter() {
-        if (f) fclose(f);
+        if (f) {  // not finished: drop the partial file
+            fclose(f);
+            (void)std::remove(tmp.c_str());
+        }
     }
     // chans[c]: the next samples of channel c (equal lengths)
     void append(const std::vector<const float *> &chans, size_t n) {
@@ -284,9 +291,14 @@ struct WavStreamWriter {
         write_wav_header(f, spec, frames);
         if (fclose(f) != 0) {
             f = nullptr;
+            (void)std::remove(tmp.c_str());
             throw std::runtime_error("closing the output file failed");
         }
         f = nullptr;
+        if (std::rename(tmp.c_str(), path.c_str()) != 0) {
+            (void)std::remove(tmp.c_str());
+            throw std::runtime_error("cannot move " + tmp + " to " + path);
+        }
     }
 };
 

@@ -28,7 +28,14 @@ namespace {
 constexpr int BIG5_T = 512, BIG5_R = 64;
 constexpr int BIG5_REGION = 2111;              // float2 slots per wave region
 constexpr int BIG5_XBUF = 8 * BIG5_REGION;
-constexpr int BIG5_TAIL_LDS = 5;               // tail pairs kept in LDS (of 32 per thread), as big4_kernel<64>
+#ifndef BIG5_TL
+#define BIG5_TL 5
+#endif
+#ifndef BIG5_K
+#define BIG5_K 4
+#endif
+constexpr int BIG5_TAIL_LDS = BIG5_TL;         // tail pairs kept in LDS (of 32 per thread), as big4_kernel<64>
+constexpr int BIG5_OVL_K = BIG5_K;             // VALU instructions per interleaved exchange store
 constexpr int BIG5_TA = 1024;                  // W_M^r, r < RES / 2
 constexpr int big5_lds_float2() { return BIG5_XBUF + BIG5_TA + 1 + 512 * BIG5_TAIL_LDS; }
 static_assert(sizeof(float2) * big5_lds_float2() <= 160 * 1024, "big5 LDS budget");
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // one DS write
-                __builtin_amdgcn_sched_group_barrier(0x2, BIG4_OVL_K, 0);  // then K VALU
+                __builtin_amdgcn_sched_group_barrier(0x2, BIG5_OVL_K, 0);  // then K VALU
             }
             __builtin_amdgcn_sched_barrier(0);
             BIG5_BAR();
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
             for (int j = 0; j < 32; ++j) lds[w0b + (j << 4)] = to_f2(v[j]);
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x2, BIG4_OVL_K, 0);  // K VALU (the butterfly that makes v[j] final)
+                __builtin_amdgcn_sched_group_barrier(0x2, BIG5_OVL_K, 0);  // K VALU (the butterfly that makes v[j] final)
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);          // then its DS write
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -473,7 +480,7 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x2, BIG4_OVL_K, 0);
+                __builtin_amdgcn_sched_group_barrier(0x2, BIG5_OVL_K, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             BIG5_BAR();

@@ -124,6 +124,14 @@ def offline_output_len(in_len: int, **kw) -> int:
     return int(_lib.lib().rc_offline_output_len(C.byref(cfg), in_len))
 
 
+class _ViewOwner:
+    """`base` of the arrays next_window_view hands out: keeps the engine alive and knows whether it is still current."""
+
+    def __init__(self, engine, channel: int, ptr: int, nbytes: int):
+        self.engine, self.channel, self.current = engine, channel, True
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, True), "version": 3}
+
+
 class _PinnedBlock:
     """Owner of one rc_host_alloc block; numpy arrays made over it keep it alive through their `base` chain."""
 
@@ -167,6 +175,8 @@ class Engine:
         self.window_len = int(self._cfg.window_len)
 
     def close(self):
+        for o in getattr(self, "_views", {}).values():
+            o.current = False
         if getattr(self, "_h", None):
             self._L.rc_engine_destroy(self._h)
             self._h = None
@@ -199,15 +209,36 @@ class Engine:
 
     def next_window_view(self, channel: int) -> Optional[np.ndarray]:
         """The same hand-out without the copy (rc_engine_next_window_view): a read-only array over the engine's
-        pinned block, valid until the next hand-out of this channel. None when the reference would block."""
+        pinned block. None when the reference would block.
+
+        LIFETIME: the array aliases memory the engine owns. It is valid only until the NEXT hand-out of this channel
+        (next_window / next_window_view) or close(): after that the block may be refilled with other windows or freed,
+        and reading a retained array is undefined (stale data or a fault) - numpy cannot be told. Consume it (write it
+        to the sink, src/main.rs:197-203) or copy it before asking for the next window; use next_window() for an array
+        you may keep. The array keeps the Engine object itself alive (its `base` chain refers to it), so garbage
+        collection never closes an engine under a live view; `view_is_current(a)` tells whether `a` is still the
+        latest hand-out of its channel."""
         p = C.POINTER(C.c_float)()
         n = C.c_size_t(0)
         rc = self._check(self._L.rc_engine_next_window_view(self._h, channel, C.byref(p), C.byref(n)))
         if rc == RC_WOULD_BLOCK:
             return None
-        a = np.ctypeslib.as_array(p, shape=(n.value,))
+        owner = _ViewOwner(self, channel, C.addressof(p.contents), n.value * 4)
+        self._views = getattr(self, "_views", {})
+        prev = self._views.get(channel)
+        if prev is not None:
+            prev.current = False
+        self._views[channel] = owner
+        a = np.asarray(owner).view(np.float32)
         a.flags.writeable = False
         return a
+
+    def view_is_current(self, a: np.ndarray) -> bool:
+        """True while `a` (from next_window_view) is the latest hand-out of its channel on an open engine."""
+        o = a
+        while o is not None and not isinstance(o, _ViewOwner):
+            o = getattr(o, "base", None)
+        return bool(o is not None and o.current and o.engine is self and self._h)
 
     def is_done(self, channel: int) -> bool:
         return bool(self._check(self._L.rc_engine_is_done(self._h, channel)))

@@ -14,7 +14,17 @@ HOST = os.path.join(ROOT, "rocoder_amd", "csrc", "host")
 BIN = os.path.join(ROOT, "rocoder_amd", "bin")
 
 
+def _need(cond, why):
+    if not cond:
+        pytest.skip(why)
+
+
 def _build(target):
+    # a box without the ROCm headers or without the sanitizer runtimes cannot build these: skip, do not fail
+    _need(os.path.exists("/opt/rocm/include/hip/hip_runtime_api.h"), "no HIP headers under /opt/rocm/include")
+    san = "asan" if target.endswith("asan") else "tsan"
+    probe = subprocess.run(["g++", f"-print-file-name=lib{san}.so"], capture_output=True, text=True)
+    _need(probe.returncode == 0 and os.path.isabs(probe.stdout.strip()), f"g++ has no lib{san}")
     subprocess.run(["make", "-s", "-f", "sanitize.mk", f"../../bin/{target}"], cwd=HOST, check=True, timeout=600)
     return os.path.join(BIN, target)
 
