@@ -435,18 +435,17 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
         case MODE_FUSED:
             if constexpr (LOG2N == 14) return launch_hop16k(p, s);  // hop4_kernel / hop2_kernel (rc_hop16k.hip)
             else {
-                // default window at 512 ... 8192: the wave-local kernels (rc_hopw.hip); the generic kernel's
-                // computed-window instantiations then exist for the shorter lengths only
+                // 512 ... 8192: the wave-local kernels (rc_hopw.hip), default window or a caller's; the generic kernel's
+                // fused instantiations then serve the shorter lengths only
                 constexpr bool WL = (LOG2N == 12 && (RC_HOPW & 1)) || (LOG2N == 13 && (RC_HOPW & 2)) || (LOG2N == 11 && (RC_HOPW & 4)) ||
                                     (LOG2N == 10 && (RC_HOPW & 8)) || (LOG2N == 9 && (RC_HOPW & 16));
                 if constexpr (WL) {
-                    if (p.hann_rot) {
-                        if constexpr (LOG2N == 12) return launch_hopw(p, s);     // one wave per hop
-                        if constexpr (LOG2N == 13) return launch_hopw2(p, s);    // two waves per hop
-                        if constexpr (LOG2N == 11) return launch_hopw11(p, s);   // one wave, 16 points per lane
-                        if constexpr (LOG2N == 10) return launch_hopw10(p, s);   // two hops per wave
-                        if constexpr (LOG2N == 9) return launch_hopw9(p, s);     // two hops per wave, 8 points per lane
-                    }
+                    // (round 5: a caller's window too - the kernels' TABW instantiations read its tables)
+                    if constexpr (LOG2N == 12) return launch_hopw(p, s);     // one wave per hop
+                    if constexpr (LOG2N == 13) return launch_hopw2(p, s);    // two waves per hop
+                    if constexpr (LOG2N == 11) return launch_hopw11(p, s);   // one wave, 16 points per lane
+                    if constexpr (LOG2N == 10) return launch_hopw10(p, s);   // two hops per wave
+                    if constexpr (LOG2N == 9) return launch_hopw9(p, s);     // two hops per wave, 8 points per lane
                 } else {
                     if (p.hann_rot && p.pitch == 1) {
                         hipLaunchKernelGGL((hop_kernel<LOG2N, MODE_FUSED, true, true>), grid, block, lds, s, p);
@@ -483,7 +482,7 @@ int hop_slots(int log2n) {  // runs per workgroup of the fused generic kernel (h
 }
 
 int hop_resident_workgroups(int log2n, bool default_window) {
-    if (!default_window) return 0;
+    (void)default_window;  // (round 5: the wave-local kernels serve a caller's window as well)
     if (log2n == 12 && (RC_HOPW & 1)) return 12;  // hopw_kernel: one wave each, three per SIMD
     if (log2n == 13 && (RC_HOPW & 2)) return 6;   // hopw2_kernel: two waves each
 #ifndef RC_HOPW11_RES

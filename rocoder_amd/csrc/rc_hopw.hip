@@ -132,11 +132,40 @@ __device__ __forceinline__ void hopw_load(GF src, unsigned lane2, float (&xr0)[P
         xr1[q] = (src + 2 * T * q)[lane2 + 1];
     }
 }
-template <int T, int m, int P = 32>
-__device__ __forceinline__ void hopw_f1x(const float (&xr0)[P], const float (&xr1)[P], v2f cb, v2f sb, const HannK32 &W, v2f (&v)[P]) {
+// TABW (round 5): a caller-supplied window - its values come from the engine's table (L2-resident: N floats) instead of
+// the per-thread rotation of the computed hanning window; `wt2` = window table + 2 x (the lane's index in its hop)
+template <int T, int m, int P = 32, bool TABW = false>
+__device__ __forceinline__ void hopw_f1x(const float (&xr0)[P], const float (&xr1)[P], v2f cb, v2f sb, const HannK32 &W, v2f (&v)[P],
+                                         GF wt2 = nullptr) {
     constexpr int LP = P == 32 ? 5 : (P == 16 ? 4 : 3), HP = P / 2;
     static_assert(P == 32 || P == 16 || P == 8, "points per lane");
     const v2f half2 = {0.5f, 0.5f};
+    if constexpr (TABW) {
+        // in batches of 4 butterflies (16 table floats in flight): with all 2 P values requested at once the 32-point kernels spill
+        constexpr int B = HP < 4 ? HP : 4;
+#pragma unroll
+        for (int q0 = 0; q0 < HP; q0 += B) {
+            float l0[B], l1[B], h0[B], h1[B];
+#pragma unroll
+            for (int q = 0; q < B; ++q) {
+                l0[q] = (wt2 + 2 * T * (q0 + q))[0];
+                l1[q] = (wt2 + 2 * T * (q0 + q))[1];
+                h0[q] = (wt2 + 2 * T * (q0 + q + HP))[0];
+                h1[q] = (wt2 + 2 * T * (q0 + q + HP))[1];
+            }
+#pragma unroll
+            for (int qq = 0; qq < B; ++qq) {
+                const int q = q0 + qq;
+                const v2f a = v2f{xr0[q], xr1[q]} * v2f{l0[qq], l1[qq]}, xh = v2f{xr0[q + HP], xr1[q + HP]};
+                const v2f wh = v2f{h0[qq], h1[qq]};
+                v[2 * brev_c(q, LP - 1)] = __builtin_elementwise_fma(xh, wh, a);
+                v[2 * brev_c(q, LP - 1) + 1] = __builtin_elementwise_fma(-xh, wh, a);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dit_stages<P, m, 1, LP - 1, 0, false, false>(v);
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < HP; ++q) {
         const v2f wl = __builtin_elementwise_fma(v2f{W.s[q], W.s[q]}, sb,
@@ -149,11 +178,11 @@ __device__ __forceinline__ void hopw_f1x(const float (&xr0)[P], const float (&xr
     }
     dit_stages<P, m, 1, LP - 1, 0, false, false>(v);
 }
-template <int T, int m, int P = 32>
-__device__ __forceinline__ void hopw_f1(GF src, unsigned lane2, v2f cb, v2f sb, const HannK32 &W, v2f (&v)[P]) {
+template <int T, int m, int P = 32, bool TABW = false>
+__device__ __forceinline__ void hopw_f1(GF src, unsigned lane2, v2f cb, v2f sb, const HannK32 &W, v2f (&v)[P], GF wt2 = nullptr) {
     float xr0[P], xr1[P];
     hopw_load<T, P>(src, lane2, xr0, xr1);
-    hopw_f1x<T, m, P>(xr0, xr1, cb, sb, W, v);
+    hopw_f1x<T, m, P, TABW>(xr0, xr1, cb, sb, W, v, wt2);
 }
 
 // The middle stage in registers: pair (A[q], B[15 - q]) = bins (r + RES q, M - that), M = 16 RES. Thread 0 owns the
@@ -220,27 +249,61 @@ __device__ __forceinline__ void hopw_middle(v2f (&va)[NS], v2f (&vb)[NS], const 
 
 // Epilogue: synthesis window (times -1/(4N)), overlap-add with the carried tail, store. cbW.. = this thread's window /
 // envelope rotations (cos, sin of beta(2 t), beta(2 t + 1)); t = the thread's index in the hop, 2 T samples per row
-template <int P>
-__device__ __forceinline__ void hopw_window(v2f (&y)[P], const v2f cbW, const v2f sbW, const HannK32 &WK, const float half_kappa) {
+template <int P, bool TABW = false, int T = 64>
+__device__ __forceinline__ void hopw_window(v2f (&y)[P], const v2f cbW, const v2f sbW, const HannK32 &WK, const float half_kappa,
+                                            GF wt2 = nullptr) {
     const v2f half2k = {half_kappa, half_kappa};
+    if constexpr (TABW) {  // the synthesis window from its table, times -1/(4N) = 2 half_kappa
+        const v2f kap = half2k + half2k;
+#pragma unroll
+        for (int q0 = 0; q0 < P; q0 += 4) {
+            float a0[4], a1[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a0[q] = (wt2 + 2 * T * (q0 + q))[0];
+                a1[q] = (wt2 + 2 * T * (q0 + q))[1];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[q0 + q] *= v2f{a0[q], a1[q]} * kap;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < P; ++q)
         y[q] *= __builtin_elementwise_fma(v2f{WK.s[q], WK.s[q]}, sbW,
                 __builtin_elementwise_fma(v2f{WK.c[q], WK.c[q]}, cbW, half2k));
 }
 // (WINDOWED: the caller has applied hopw_window already - hopw10_kernel, which fetches the other half-wave's tail between)
-template <int PITCHC, int T, int P = 32, bool WINDOWED = false>
+// TABW: wt2 / et2 = window / envelope table + 2 x (the lane's index in its hop): the values of a caller's window
+template <int PITCHC, int T, int P = 32, bool WINDOWED = false, bool TABW = false>
 __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, const int64_t k, const bool emit, const int t,
                                               v2f (&y)[P], v2f (&tail)[P / 2], const v2f cbW, const v2f sbW, v2f cbE,
                                               v2f sbE, const HannK32 &WK, const HannK32 &E, const float half_kappa,
-                                              const uint32_t pitch) {
+                                              const uint32_t pitch, GF wt2 = nullptr, GF et2 = nullptr) {
     constexpr int PH = P / 2, H = T * P;
     constexpr bool PITCH1 = PITCHC == 1;
     const v2f half2 = {0.5f, 0.5f};
     const unsigned lane2 = 2u * (unsigned)t;
-    if (!WINDOWED) hopw_window<P>(y, cbW, sbW, WK, half_kappa);
+    if (!WINDOWED) hopw_window<P, TABW, T>(y, cbW, sbW, WK, half_kappa, wt2);
     if (emit) {
         const v2f amp2 = {p.amp, p.amp};
+        if constexpr (TABW) {
+            // (y + tail) * env * amp with the envelope from its table, in place and in batches of 4 rows (all PH rows
+            // requested at once spill at 32 points per lane); the store loops below then take y[q] as it is
+#pragma unroll
+            for (int q0 = 0; q0 < PH; q0 += 4) {
+                float e0[4], e1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    e0[q] = (et2 + 2 * T * (q0 + q))[0];
+                    e1[q] = (et2 + 2 * T * (q0 + q))[1];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[q0 + q] = (y[q0 + q] + tail[q0 + q]) * v2f{e0[q], e1[q]} * amp2;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         // env[i] * amp = amp/2 + c_q (amp cb) + s_q (amp sb): the amplitude rides on the per-thread rotation
         cbE *= amp2;
         sbE *= amp2;
@@ -255,7 +318,7 @@ __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, cons
             for (int q = 0; q < PH; ++q) {
                 const v2f er = __builtin_elementwise_fma(v2f{E.s[q], E.s[q]}, sbE,
                                __builtin_elementwise_fma(v2f{E.c[q], E.c[q]}, cbE, halfa));
-                const v2f o = (y[q] + tail[q]) * er;  // (y + tail) * (env * amp), stretcher.rs:97-100
+                const v2f o = TABW ? y[q] : (y[q] + tail[q]) * er;  // (y + tail) * (env * amp), stretcher.rs:97-100
                 __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));  // (plain stores: +2 % at 2048 / 8192)
             }
         } else {
@@ -274,7 +337,7 @@ __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, cons
                 for (int q = 0; q < PH; ++q) {
                     const v2f er = __builtin_elementwise_fma(v2f{E.s[q], E.s[q]}, sbE,
                                    __builtin_elementwise_fma(v2f{E.c[q], E.c[q]}, cbE, halfa));
-                    const v2f o = (y[q] + tail[q]) * er;
+                    const v2f o = TABW ? y[q] : (y[q] + tail[q]) * er;
                     const float ox = o.x, oy = o.y;
                     pitch_store_pair<PITCHC, 2 * T>(rsrc, po, q, ox, oy);
                 }
@@ -288,7 +351,7 @@ __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, cons
             for (int q = 0; q < PH; ++q) {
                 const v2f er = __builtin_elementwise_fma(v2f{E.s[q], E.s[q]}, sbE,
                                __builtin_elementwise_fma(v2f{E.c[q], E.c[q]}, cbE, halfa));
-                const v2f o = (y[q] + tail[q]) * er;
+                const v2f o = TABW ? y[q] : (y[q] + tail[q]) * er;
                 const float ox = o.x, oy = o.y;
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ox), rsrc, rr == 0 ? d4 : DROP, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(oy), rsrc, rr + 1 == pitch ? d4 + 4u : DROP, 0, 0);
@@ -306,7 +369,7 @@ __device__ __forceinline__ void hopw_epilogue(const HopParams &p, GFW outc, cons
     for (int q = 0; q < PH; ++q) tail[q] = y[q + PH];
 }
 
-template <int PITCHC>  // 1: pitch 1; 2 / 3: that pitch at compile time; 0: any pitch > 1 from HopParams
+template <int PITCHC, bool TABW = false>  // PITCHC 1: pitch 1; 2 / 3: that pitch at compile time; 0: any pitch > 1; TABW: a caller's window (tables)
 __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
     constexpr int LOG2N = 12, m = 11, T = 64, P = 32, PH = 16, RES = 128;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -336,12 +399,14 @@ __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
             lds[HW_TB + tid] = ldg2(wt + 16 * tid);
             lds[HW_TC + tid] = ldg2(wt + 32 * tid);
         }
+        if constexpr (!TABW) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {  // hann_rot: [part][lane][4] = {cos, sin}(beta(2t)), {cos, sin}(beta(2t + 1))
             const float2 a = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid);
             const float2 b = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid + 1);
             lds[HW_TH + 128 * i + 2 * tid] = make_float2(a.x, b.x);      // (cos beta_0, cos beta_1)
             lds[HW_TH + 128 * i + 2 * tid + 1] = make_float2(a.y, b.y);  // (sin beta_0, sin beta_1)
+        }
         }
         __syncthreads();
     }
@@ -360,7 +425,8 @@ __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
     for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         v2f v[P];
-        hopw_f1<T, m>(hop_src(p, xc, xt, k), lane2, to_v(lds[HW_TH + 2 * tid]), to_v(lds[HW_TH + 2 * tid + 1]), HANN_W12, v);
+        hopw_f1<T, m, P, TABW>(hop_src(p, xc, xt, k), lane2, to_v(lds[HW_TH + 2 * tid]), to_v(lds[HW_TH + 2 * tid + 1]), HANN_W12, v,
+                               TABW ? per_hop(p.window) + lane2 : nullptr);
         // ---- E1: registers P0..P4 -> P4..P8, round = P4. Weights: P0 16, P1 33, P2 66, P3 136, P5 272, P6 544,
         // P7 1, P8 2, P9 4, P10 8 (lane t: P5 = t5 ... P10 = t0)
         v2f w2[P];
@@ -480,9 +546,10 @@ __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
 
         {
             const int t = lane();
-            hopw_epilogue<PITCHC, T>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[HW_TH + 2 * t]), to_v(lds[HW_TH + 2 * t + 1]),
+            hopw_epilogue<PITCHC, T, P, false, TABW>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[HW_TH + 2 * t]), to_v(lds[HW_TH + 2 * t + 1]),
                                      to_v(lds[HW_TH + 128 + 2 * t]), to_v(lds[HW_TH + 128 + 2 * t + 1]), HANN_W12K, HANN_E12,
-                                     (float)(0.5 * HANN_KAPPA12), pitch);
+                                     (float)(0.5 * HANN_KAPPA12), pitch, TABW ? per_hop(p.window) + 2 * t : nullptr,
+                                     TABW ? per_hop(p.env) + 2 * t : nullptr);
         }
     }
 }
@@ -498,7 +565,7 @@ __global__ __launch_bounds__(64, 3) void hopw_kernel(const HopParams p) {
 #ifndef RC_HOPW11_WPS
 #define RC_HOPW11_WPS 3  // register budget of three waves per SIMD: the allocator takes 112 VGPRs (four still fit; with the budget of four it takes 94 and the kernel is 6 % slower)
 #endif
-template <int PITCHC>
+template <int PITCHC, bool TABW = false>
 __global__ __launch_bounds__(64, RC_HOPW11_WPS) void hopw11_kernel(const HopParams p) {
     constexpr int LOG2N = 11, m = 10, T = 64, P = 16, PH = 8, RES = 128, NS = 8;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -528,12 +595,14 @@ __global__ __launch_bounds__(64, RC_HOPW11_WPS) void hopw11_kernel(const HopPara
             lds[H1_TB + tid] = ldg2(wt + 8 * tid);        // W_128^l
             lds[H1_TC + tid] = ldg2(wt + 16 * tid);       // W_64^l
         }
+        if constexpr (!TABW) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float2 a = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid);
             const float2 b = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid + 1);
             lds[H1_TH + 128 * i + 2 * tid] = make_float2(a.x, b.x);
             lds[H1_TH + 128 * i + 2 * tid + 1] = make_float2(a.y, b.y);
+        }
         }
         __syncthreads();
     }
@@ -556,7 +625,8 @@ __global__ __launch_bounds__(64, RC_HOPW11_WPS) void hopw11_kernel(const HopPara
     for (int64_t k = k_first; k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         v2f v[P];
-        hopw_f1x<T, m, P>(xr0, xr1, to_v(lds[H1_TH + 2 * tid]), to_v(lds[H1_TH + 2 * tid + 1]), HANN_W11, v);
+        hopw_f1x<T, m, P, TABW>(xr0, xr1, to_v(lds[H1_TH + 2 * tid]), to_v(lds[H1_TH + 2 * tid + 1]), HANN_W11, v,
+                                TABW ? per_hop(p.window) + lane2 : nullptr);
         // ---- E1: registers P0..P3 -> P3..P6, round = P3. Weights: P9 1, P8 2, P7 4, P6 8, P0 16, P1 33, P2 72, P4 137,
         // P5 274 (lane t: P4 = t5 ... P9 = t0)
         v2f w2[P];
@@ -668,9 +738,10 @@ __global__ __launch_bounds__(64, RC_HOPW11_WPS) void hopw11_kernel(const HopPara
         dit_stages<16, m, 6, 9, 6, true, true>(y, to_v(lds[H1_TA + lane()]));
         {
             const int t = lane();
-            hopw_epilogue<PITCHC, T, P>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[H1_TH + 2 * t]), to_v(lds[H1_TH + 2 * t + 1]),
+            hopw_epilogue<PITCHC, T, P, false, TABW>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[H1_TH + 2 * t]), to_v(lds[H1_TH + 2 * t + 1]),
                                         to_v(lds[H1_TH + 128 + 2 * t]), to_v(lds[H1_TH + 128 + 2 * t + 1]), HANN_W11K, HANN_E11,
-                                        (float)(0.5 * HANN_KAPPA11), pitch);
+                                        (float)(0.5 * HANN_KAPPA11), pitch, TABW ? per_hop(p.window) + 2 * t : nullptr,
+                                        TABW ? per_hop(p.env) + 2 * t : nullptr);
         }
         if (!RC_HOPW_PREFETCH) hopw_load<T, P>(hop_src(p, xc, xt, k + 1 < k_end ? k + 1 : k), lane2, xr0, xr1);
     }
@@ -684,7 +755,7 @@ __global__ __launch_bounds__(64, RC_HOPW11_WPS) void hopw11_kernel(const HopPara
 // The hop index, the phase key, the source pointer and the store offsets are per lane. Overlap-add across the halves:
 // the upper half's head takes the lower half's tail of the same iteration, the lower half's head the upper half's tail of
 // the iteration before - one v_permlane32_swap per register moves both.
-template <int PITCHC>
+template <int PITCHC, bool TABW = false>
 __global__ __launch_bounds__(64, 3) void hopw10_kernel(const HopParams p) {
     constexpr int LOG2N = 10, m = 9, T = 32, P = 16, PH = 8, RES = 64, NS = 8;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -711,7 +782,7 @@ __global__ __launch_bounds__(64, 3) void hopw10_kernel(const HopParams p) {
             lds[H0_TB + tid] = ldg2(wt + 8 * tid);    // W_64^l
             lds[H0_TC + tid] = ldg2(wt + 16 * tid);   // W_32^l
         }
-        if (tid < 32) {
+        if (!TABW && tid < 32) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {  // hann_rot: [part][64 threads][4]; the 32 lanes of a hop are threads 0..31
                 const float2 a = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid);
@@ -745,7 +816,8 @@ __global__ __launch_bounds__(64, 3) void hopw10_kernel(const HopParams p) {
             const int tl = tid & 31;
             float xr0[P], xr1[P];
             hopw_load<T, P>(hop_src_lane(p, xc, xt, kc), 2u * (unsigned)tl, xr0, xr1);
-            hopw_f1x<T, m, P>(xr0, xr1, to_v(lds[H0_TH + 2 * tl]), to_v(lds[H0_TH + 2 * tl + 1]), HANN_W10, v);
+            hopw_f1x<T, m, P, TABW>(xr0, xr1, to_v(lds[H0_TH + 2 * tl]), to_v(lds[H0_TH + 2 * tl + 1]), HANN_W10, v,
+                                    TABW ? per_hop(p.window) + 2 * tl : nullptr);
         }
         // ---- E1: registers P0..P3 -> P3..P6, round = P3. Weights: P8 1, P7 2, P6 4, P5 8, P0 16, P1 36, P2 72, P4 140
         // (lane t of the half: P4 = t4 ... P8 = t0)
@@ -856,7 +928,8 @@ __global__ __launch_bounds__(64, 3) void hopw10_kernel(const HopParams p) {
         dit_stages<16, m, 5, 8, 5, true, true>(y, to_v(lds[H0_TA + (lane() & 31)]));
         {
             const int t = lane(), tl = t & 31, up = t >> 5;
-            hopw_window<P>(y, to_v(lds[H0_TH + 2 * tl]), to_v(lds[H0_TH + 2 * tl + 1]), HANN_W10K, (float)(0.5 * HANN_KAPPA10));
+            hopw_window<P, TABW, T>(y, to_v(lds[H0_TH + 2 * tl]), to_v(lds[H0_TH + 2 * tl + 1]), HANN_W10K, (float)(0.5 * HANN_KAPPA10),
+                                    TABW ? per_hop(p.window) + 2 * tl : nullptr);
             // the tail this lane's head overlaps: lower half <- upper half's tail of the iteration before (carried in
             // `tail`), upper half <- lower half's tail of this iteration. v_permlane32_swap(a, b): a = (a.lo, b.lo),
             // b = (a.hi, b.hi) over the two half-waves
@@ -870,9 +943,10 @@ __global__ __launch_bounds__(64, 3) void hopw10_kernel(const HopParams p) {
                 tail[q] = y[PH + q];
             }
             // stores: the iteration's base is hop kk (uniform); the upper half's samples lie H = 512 further on
-            hopw_epilogue<PITCHC, T, P, true>(p, outc, kk, valid && k >= k_begin, tl + 256 * up, y, tin,
+            hopw_epilogue<PITCHC, T, P, true, TABW>(p, outc, kk, valid && k >= k_begin, tl + 256 * up, y, tin,
                                               v2f{0.f, 0.f}, v2f{0.f, 0.f}, to_v(lds[H0_TH + 64 + 2 * tl]),
-                                              to_v(lds[H0_TH + 64 + 2 * tl + 1]), HANN_W10K, HANN_E10, 0.0f, pitch);
+                                              to_v(lds[H0_TH + 64 + 2 * tl + 1]), HANN_W10K, HANN_E10, 0.0f, pitch, nullptr,
+                                              TABW ? per_hop(p.env) + 2 * tl : nullptr);
         }
     }
 }
@@ -881,7 +955,7 @@ __global__ __launch_bounds__(64, 3) void hopw10_kernel(const HopParams p) {
 // hopw10_kernel's arrangement with passes of (3, 3, 2) / (2, 3, 3) stages: every pass uses all three register bits, so an
 // exchange is ONE round of 8 stores + 8 loads per lane through 284 float2 per half (tests/dev/proto_w9.py); two sets of 4
 // registers around the pair stage (lane tau of a half holds residues tau and 64 - tau).
-template <int PITCHC>
+template <int PITCHC, bool TABW = false>
 __global__ __launch_bounds__(64, 4) void hopw9_kernel(const HopParams p) {
     constexpr int LOG2N = 9, m = 8, T = 32, P = 8, PH = 4, RES = 64, NS = 4;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -906,7 +980,7 @@ __global__ __launch_bounds__(64, 4) void hopw9_kernel(const HopParams p) {
         }
         if (tid < 8) lds[H9_TB + tid] = ldg2(wt + 4 * tid);   // W_64^l
         if (tid < 4) lds[H9_TC + tid] = ldg2(wt + 8 * tid);   // W_32^l
-        if (tid < 32) {
+        if (!TABW && tid < 32) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {  // hann_rot: [part][64 threads][4]; the 32 lanes of a hop are threads 0..31
                 const float2 a = ldg2((GV2)p.hann_rot + 128 * i + 2 * tid);
@@ -940,7 +1014,8 @@ __global__ __launch_bounds__(64, 4) void hopw9_kernel(const HopParams p) {
             const int tl = tid & 31;
             float xr0[P], xr1[P];
             hopw_load<T, P>(hop_src_lane(p, xc, xt, kc), 2u * (unsigned)tl, xr0, xr1);
-            hopw_f1x<T, m, P>(xr0, xr1, to_v(lds[H9_TH + 2 * tl]), to_v(lds[H9_TH + 2 * tl + 1]), HANN_W9, v);
+            hopw_f1x<T, m, P, TABW>(xr0, xr1, to_v(lds[H9_TH + 2 * tl]), to_v(lds[H9_TH + 2 * tl + 1]), HANN_W9, v,
+                                    TABW ? per_hop(p.window) + 2 * tl : nullptr);
         }
         // ---- E1: registers P0..P2 -> P3..P5. Weights: P7 1 ... P3 16 (= the lane as it stands), P0 36, P1 72, P2 144
         v2f w2[P];
@@ -1030,7 +1105,8 @@ __global__ __launch_bounds__(64, 4) void hopw9_kernel(const HopParams p) {
         dit_stages<8, m, 5, 7, 5, true, true>(y, to_v(lds[H9_TA + (lane() & 31)]));
         {
             const int t = lane(), tl = t & 31, up = t >> 5;
-            hopw_window<P>(y, to_v(lds[H9_TH + 2 * tl]), to_v(lds[H9_TH + 2 * tl + 1]), HANN_W9K, (float)(0.5 * HANN_KAPPA9));
+            hopw_window<P, TABW, T>(y, to_v(lds[H9_TH + 2 * tl]), to_v(lds[H9_TH + 2 * tl + 1]), HANN_W9K, (float)(0.5 * HANN_KAPPA9),
+                                    TABW ? per_hop(p.window) + 2 * tl : nullptr);
             v2f tin[PH];  // (hopw10_kernel: the other half-wave's tail)
 #pragma unroll
             for (int q = 0; q < PH; ++q) {
@@ -1040,9 +1116,10 @@ __global__ __launch_bounds__(64, 4) void hopw9_kernel(const HopParams p) {
                 tin[q] = up ? v2f{ax, ay} : v2f{bx, by};
                 tail[q] = y[PH + q];
             }
-            hopw_epilogue<PITCHC, T, P, true>(p, outc, kk, valid && k >= k_begin, tl + 128 * up, y, tin,
+            hopw_epilogue<PITCHC, T, P, true, TABW>(p, outc, kk, valid && k >= k_begin, tl + 128 * up, y, tin,
                                               v2f{0.f, 0.f}, v2f{0.f, 0.f}, to_v(lds[H9_TH + 64 + 2 * tl]),
-                                              to_v(lds[H9_TH + 64 + 2 * tl + 1]), HANN_W9K, HANN_E9, 0.0f, pitch);
+                                              to_v(lds[H9_TH + 64 + 2 * tl + 1]), HANN_W9K, HANN_E9, 0.0f, pitch, nullptr,
+                                              TABW ? per_hop(p.env) + 2 * tl : nullptr);
         }
     }
 }
@@ -1057,7 +1134,7 @@ __global__ __launch_bounds__(64, 4) void hopw9_kernel(const HopParams p) {
 //   (lane = P1..P3, P9..P11), F3 stages 8..11 on two sets of 16 (thread tau = 2 lane + wave holds residues tau and
 //   256 - tau; thread 0: residues 0 and 128); I1 stages 0..3, I2 stages 4..6 on registers Q4..Q8, I3 stages 7..11 on
 //   registers Q7..Q11 (thread = Q0..Q6).
-template <int PITCHC>  // 1: pitch 1; 2 / 3: that pitch at compile time; 0: any pitch > 1 from HopParams
+template <int PITCHC, bool TABW = false>
 __global__ __launch_bounds__(128, 3) void hopw2_kernel(const HopParams p) {
     constexpr int LOG2N = 13, m = 12, T = 128, P = 32, PH = 16, RES = 256, HALF = H2_BUF / 2;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
@@ -1086,12 +1163,14 @@ __global__ __launch_bounds__(128, 3) void hopw2_kernel(const HopParams p) {
             lds[H2_TB + tid] = ldg2(wt + 16 * tid);       // W_256^l
             lds[H2_TC + tid] = ldg2(wt + 32 * tid);       // W_128^l
         }
+        if constexpr (!TABW) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {  // hann_rot: [part][thread][4] = {cos, sin}(beta(2t)), {cos, sin}(beta(2t + 1))
             const float2 a = ldg2((GV2)p.hann_rot + 256 * i + 2 * tid);
             const float2 b = ldg2((GV2)p.hann_rot + 256 * i + 2 * tid + 1);
             lds[H2_TH + 256 * i + 2 * tid] = make_float2(a.x, b.x);      // (cos beta_0, cos beta_1)
             lds[H2_TH + 256 * i + 2 * tid + 1] = make_float2(a.y, b.y);  // (sin beta_0, sin beta_1)
+        }
         }
         __syncthreads();
     }
@@ -1108,7 +1187,8 @@ __global__ __launch_bounds__(128, 3) void hopw2_kernel(const HopParams p) {
     for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         v2f v[P];
-        hopw_f1<T, m>(hop_src(p, xc, xt, k), lane2, to_v(lds[H2_TH + 2 * tid]), to_v(lds[H2_TH + 2 * tid + 1]), HANN_W13, v);
+        hopw_f1<T, m, P, TABW>(hop_src(p, xc, xt, k), lane2, to_v(lds[H2_TH + 2 * tid]), to_v(lds[H2_TH + 2 * tid + 1]), HANN_W13, v,
+                               TABW ? per_hop(p.window) + lane2 : nullptr);
         // ---- E1 (cross-wave): registers P0..P4 -> P4..P8, round = P4. Weights: P8 1, P9 2, P10 4, P11 8, P1 16, P2 33,
         // P3 72, P0 144, P5 288, P6 576, P7 1152 (writer: wave = P5, lane: P6 = bit 5 ... P11 = bit 0)
         v2f w2[P];
@@ -1236,9 +1316,10 @@ __global__ __launch_bounds__(128, 3) void hopw2_kernel(const HopParams p) {
         dit_stages<32, m, 7, 11, 7, true, true>(y, to_v(lds[H2_TA + thread()]));
         {
             const int t = thread();
-            hopw_epilogue<PITCHC, T>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[H2_TH + 2 * t]), to_v(lds[H2_TH + 2 * t + 1]),
+            hopw_epilogue<PITCHC, T, P, false, TABW>(p, outc, k, k >= k_begin, t, y, tail, to_v(lds[H2_TH + 2 * t]), to_v(lds[H2_TH + 2 * t + 1]),
                                      to_v(lds[H2_TH + 256 + 2 * t]), to_v(lds[H2_TH + 256 + 2 * t + 1]), HANN_W13K, HANN_E13,
-                                     (float)(0.5 * HANN_KAPPA13), pitch);
+                                     (float)(0.5 * HANN_KAPPA13), pitch, TABW ? per_hop(p.window) + 2 * t : nullptr,
+                                     TABW ? per_hop(p.env) + 2 * t : nullptr);
         }
     }
 }
@@ -1251,6 +1332,12 @@ size_t hopw_lds_bytes() { return sizeof(float2) * (size_t)HOPW_LDS_FLOAT2; }
 hipError_t launch_hopw(const HopParams &p, hipStream_t s) {
     const dim3 grid(p.runs_per_channel * p.n_channels), block(64);
     const size_t lds = sizeof(float2) * (size_t)HOPW_LDS_FLOAT2;
+    if (!p.hann_rot) {  // a caller's window: its table values (pitch 1, or any pitch at run time)
+        if (!p.window || !p.env) return hipErrorInvalidValue;  // (the TABW kernels dereference both tables)
+        if (p.pitch == 1) hipLaunchKernelGGL((hopw_kernel<1, true>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((hopw_kernel<0, true>), grid, block, lds, s, p);
+        return hipGetLastError();
+    }
     if (p.pitch == 1) hipLaunchKernelGGL((hopw_kernel<1>), grid, block, lds, s, p);
     else if (p.pitch == 2) hipLaunchKernelGGL((hopw_kernel<2>), grid, block, lds, s, p);
     else if (p.pitch == 3) hipLaunchKernelGGL((hopw_kernel<3>), grid, block, lds, s, p);
@@ -1262,6 +1349,12 @@ hipError_t launch_hopw(const HopParams &p, hipStream_t s) {
 hipError_t launch_hopw9(const HopParams &p, hipStream_t s) {
     const dim3 grid(p.runs_per_channel * p.n_channels), block(64);
     const size_t lds = sizeof(float2) * (size_t)HOPW9_LDS_FLOAT2;
+    if (!p.hann_rot) {  // a caller's window: its table values (pitch 1, or any pitch at run time)
+        if (!p.window || !p.env) return hipErrorInvalidValue;  // (the TABW kernels dereference both tables)
+        if (p.pitch == 1) hipLaunchKernelGGL((hopw9_kernel<1, true>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((hopw9_kernel<0, true>), grid, block, lds, s, p);
+        return hipGetLastError();
+    }
     if (p.pitch == 1) hipLaunchKernelGGL((hopw9_kernel<1>), grid, block, lds, s, p);
     else if (p.pitch == 2) hipLaunchKernelGGL((hopw9_kernel<2>), grid, block, lds, s, p);
     else if (p.pitch == 3) hipLaunchKernelGGL((hopw9_kernel<3>), grid, block, lds, s, p);
@@ -1273,6 +1366,12 @@ hipError_t launch_hopw9(const HopParams &p, hipStream_t s) {
 hipError_t launch_hopw10(const HopParams &p, hipStream_t s) {
     const dim3 grid(p.runs_per_channel * p.n_channels), block(64);
     const size_t lds = sizeof(float2) * (size_t)HOPW10_LDS_FLOAT2;
+    if (!p.hann_rot) {  // a caller's window: its table values (pitch 1, or any pitch at run time)
+        if (!p.window || !p.env) return hipErrorInvalidValue;  // (the TABW kernels dereference both tables)
+        if (p.pitch == 1) hipLaunchKernelGGL((hopw10_kernel<1, true>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((hopw10_kernel<0, true>), grid, block, lds, s, p);
+        return hipGetLastError();
+    }
     if (p.pitch == 1) hipLaunchKernelGGL((hopw10_kernel<1>), grid, block, lds, s, p);
     else if (p.pitch == 2) hipLaunchKernelGGL((hopw10_kernel<2>), grid, block, lds, s, p);
     else if (p.pitch == 3) hipLaunchKernelGGL((hopw10_kernel<3>), grid, block, lds, s, p);
@@ -1284,6 +1383,12 @@ hipError_t launch_hopw10(const HopParams &p, hipStream_t s) {
 hipError_t launch_hopw11(const HopParams &p, hipStream_t s) {
     const dim3 grid(p.runs_per_channel * p.n_channels), block(64);
     const size_t lds = sizeof(float2) * (size_t)HOPW11_LDS_FLOAT2;
+    if (!p.hann_rot) {  // a caller's window: its table values (pitch 1, or any pitch at run time)
+        if (!p.window || !p.env) return hipErrorInvalidValue;  // (the TABW kernels dereference both tables)
+        if (p.pitch == 1) hipLaunchKernelGGL((hopw11_kernel<1, true>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((hopw11_kernel<0, true>), grid, block, lds, s, p);
+        return hipGetLastError();
+    }
     if (p.pitch == 1) hipLaunchKernelGGL((hopw11_kernel<1>), grid, block, lds, s, p);
     else if (p.pitch == 2) hipLaunchKernelGGL((hopw11_kernel<2>), grid, block, lds, s, p);
     else if (p.pitch == 3) hipLaunchKernelGGL((hopw11_kernel<3>), grid, block, lds, s, p);
@@ -1295,6 +1400,12 @@ hipError_t launch_hopw11(const HopParams &p, hipStream_t s) {
 hipError_t launch_hopw2(const HopParams &p, hipStream_t s) {
     const dim3 grid(p.runs_per_channel * p.n_channels), block(128);
     const size_t lds = sizeof(float2) * (size_t)HOPW2_LDS_FLOAT2;
+    if (!p.hann_rot) {  // a caller's window: its table values (pitch 1, or any pitch at run time)
+        if (!p.window || !p.env) return hipErrorInvalidValue;  // (the TABW kernels dereference both tables)
+        if (p.pitch == 1) hipLaunchKernelGGL((hopw2_kernel<1, true>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((hopw2_kernel<0, true>), grid, block, lds, s, p);
+        return hipGetLastError();
+    }
     if (p.pitch == 1) hipLaunchKernelGGL((hopw2_kernel<1>), grid, block, lds, s, p);
     else if (p.pitch == 2) hipLaunchKernelGGL((hopw2_kernel<2>), grid, block, lds, s, p);
     else if (p.pitch == 3) hipLaunchKernelGGL((hopw2_kernel<3>), grid, block, lds, s, p);

@@ -1475,3 +1475,39 @@ def test_big5_agrees_with_big4_at_window_65536(monkeypatch, ch, L, table_window,
         assert ref_rms > 0.01
         assert float(d.pow(2).mean().sqrt()) <= 1e-6 * ref_rms, (c, float(d.pow(2).mean().sqrt()) / ref_rms)
         assert float(d.abs().max()) <= 2e-5, c
+
+
+@pytest.mark.parametrize("N,f,p,ch,L", [
+    (512, 8.0, 1, 2, 40_000), (512, 2.0, 2, 3, 20_001), (512, 0.3, 1, 1, 30_000),
+    (1024, 8.0, 1, 2, 70_000), (1024, 4.0, 3, 1, 33_333), (1024, 1.0, 5, 2, 25_000),
+    (2048, 8.0, 1, 2, 120_000), (2048, 3.0, 2, 2, 50_001), (2048, 16.0, 1, 5, 30_000),
+    (4096, 8.0, 1, 2, 250_000), (4096, 4.0, 3, 1, 99_999), (4096, 0.25, 1, 2, 200_000),
+    (8192, 8.0, 1, 2, 400_000), (8192, 2.0, 2, 3, 150_001), (8192, 8.0, 7, 1, 120_000),
+    (4096, 8.0, 1, 1, 4095), (2048, 8.0, 1, 2, 0),
+])
+def test_caller_window_on_the_wave_local_kernels(N, f, p, ch, L):
+    """A caller-supplied window at 512 ... 8192 (round 5: the TABW instantiations of hopw9 / hopw10 / hopw11 / hopw /
+    hopw2, which read the engine's window and envelope tables instead of rotating the computed hanning window) against
+    the oracle driven with the same window: pitch 1 (compile-time) and other pitches (run-time), several channels,
+    ragged lengths, a job shorter than a window, an empty one."""
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, L) for c in range(ch)]) if L else np.zeros((ch, 0), np.float32)
+    w = (oc.hanning(N).astype(np.float64) ** 1.5).astype(np.float32)
+    with ra.Engine(window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=3, window=w) as e:
+        got = e.stretch_host(x)
+    chans = []
+    for c in range(ch):
+        st = oc.Stretcher(channels=ch, factor=f, pitch_multiple=p, window=w, seed=3, channel_index=c)
+        st.send(x[c])
+        st.close_input()
+        wins = []
+        while not st.is_done():
+            wins.append(st.next_window())
+        chans.append(np.concatenate(wins))
+    ref = np.stack(chans)
+    assert got.shape == ref.shape
+    for c in range(ch):
+        if L:
+            assert_parity(got[c], ref[c], f"table window N={N} f={f} p={p} ch={c}")
+        else:
+            assert np.array_equal(got[c], ref[c])

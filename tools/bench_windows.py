@@ -20,8 +20,8 @@ clk = ClockSampler(0)
 clk.__enter__()
 with torch.cuda.stream(stream):
     # "t" rows: a caller-supplied window (hanning ** 1.5: not the default, so the table-window kernels run -
-    # hop2_kernel at 16384, the generic hop_kernel below)
-    for N in (64, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 12000, 24000, "16384t", "4096t", "1024t"):
+    # hop2_kernel at 16384, the TABW instantiations of the wave-local kernels at 512 ... 8192 since round 5)
+    for N in (64, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 12000, 24000, "16384t", "8192t", "4096t", "2048t", "1024t", "512t"):
         table = isinstance(N, str)
         tag = N
         N = int(N[:-1]) if table else N

@@ -13,4 +13,8 @@ step() {
     echo "[$name rc=$rc]"
     tail -n 6 "gpurun_out/$name.log"
     if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then STOP=1; fi
+    # a GPU fault (an out-of-bounds access in a kernel) ends the sequence too: nothing else runs on that box
+    if grep -q "Memory access fault\|HSA_STATUS_ERROR\|GPU core dump" "gpurun_out/$name.log"; then STOP=1; FAULT=1; fi
 }
+FAULT=0
+finish() { if [ "$FAULT" != 0 ]; then echo "[a step faulted on the GPU]"; exit 1; fi; exit 0; }

@@ -6,4 +6,4 @@ step 120 r05a_bench_gpus2 python bench.py --gpus 2
 ROCODER_BENCH_REHEARSAL=1 step 600 r05a_rehearsal4 python bench.py --gpus 4 --steps 5 --warmup 2
 step 600 r05a_e2e_host python tests/dev/e2e_host.py
 grep -h '^{' gpurun_out/r05a_bench.log > gpurun_out/r05a_bench.json
-exit 0
+finish

@@ -2,4 +2,4 @@
 source tools/gpu_steps.sh
 step 1100 r05e_profile_c2 tools/profile_round.sh r05a pmc
 step 900 r05e_profile_c5 tools/profile_c5.sh r05a_c5
-exit 0
+finish
