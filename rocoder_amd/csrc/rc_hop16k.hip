@@ -433,9 +433,12 @@ __device__ __forceinline__ float band_gain(const HopParams &p, uint32_t f) {
     return (f - p.band_lo) <= p.band_span ? p.band_gin : p.band_gout;
 }
 // PITCHC: 1 = pitch 1, 2 / 3 = that pitch at compile time (pitch_store_pair), 0 = any pitch > 1 from HopParams
-template <int PITCHC, bool BAND = false>
+// TABW (round 5, pitch 1 only): a caller's window - analysis / synthesis window and envelope values come from the engine's
+// tables (L2-resident) in batches of 4 rows instead of the rotation of the computed hanning window
+template <int PITCHC, bool BAND = false, bool TABW = false>
 __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
     constexpr bool PITCH1 = PITCHC == 1;
+    static_assert(!TABW || (PITCH1 && !BAND), "the table-window instantiation exists for pitch 1 without the band mask");
     constexpr int LOG2N = 14, m = 13, M = 1 << m, H = M, T = 256, P = 32, PH = 16;
     constexpr int RES = 512, REG = HOP4_REG;
     constexpr int SCR = HOP4_XBUF + 8;
@@ -544,12 +547,14 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             const float2 w256 = ldg2((GV2)p.rtab + 256);
             lds[SCR + 2] = make_float2(-w256.y, w256.x);
         }
+        if constexpr (!TABW) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float2 a = ldg2((GV2)p.hann_rot + 512 * i + 2 * tid);
-            const float2 b = ldg2((GV2)p.hann_rot + 512 * i + 2 * tid + 1);
-            lds[T_H + 512 * i + 2 * tid] = make_float2(a.x, b.x);
-            lds[T_H + 512 * i + 2 * tid + 1] = make_float2(a.y, b.y);
+            for (int i = 0; i < 2; ++i) {
+                const float2 a = ldg2((GV2)p.hann_rot + 512 * i + 2 * tid);
+                const float2 b = ldg2((GV2)p.hann_rot + 512 * i + 2 * tid + 1);
+                lds[T_H + 512 * i + 2 * tid] = make_float2(a.x, b.x);
+                lds[T_H + 512 * i + 2 * tid + 1] = make_float2(a.y, b.y);
+            }
         }
         __syncthreads();
     }
@@ -566,6 +571,25 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);  // (the builtin returns int:
             const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));  // widen as unsigned)
             GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
+            if constexpr (TABW) {
+                GF et2 = per_hop(p.env) + lane2;
+#pragma unroll
+                for (int q0 = 0; q0 < PH; q0 += 4) {
+                    float e0[4], e1[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        e0[q] = (et2 + 2 * T * (q0 + q))[0];
+                        e1[q] = (et2 + 2 * T * (q0 + q))[1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const v2f o = (head[q0 + q] + tail[q0 + q]) * v2f{e0[q], e1[q]} * amp2;  // stretcher.rs:97-100
+                        __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * (q0 + q) + lane2));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < PH; ++q) {
                 const v2f er = __builtin_elementwise_fma(v2f{HANN_E14.s[q], HANN_E14.s[q]}, sbE,
@@ -649,6 +673,29 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             const v2f cb = to_v(lds[T_H + 2 * tid]), sb = to_v(lds[T_H + 2 * tid + 1]);
             // stage 0 pairs registers brev5(q) and brev5(q + 16) = brev5(q) + 1: a +- b with a = x_q w_q and
             // b = x_{q+16} w_{q+16} is one multiply and two FMAs
+            if constexpr (TABW) {
+                GF wt2 = per_hop(p.window) + lane2;
+#pragma unroll
+                for (int q0 = 0; q0 < 16; q0 += 4) {
+                    float l0[4], l1[4], h0[4], h1[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        l0[q] = (wt2 + 2 * T * (q0 + q))[0];
+                        l1[q] = (wt2 + 2 * T * (q0 + q))[1];
+                        h0[q] = (wt2 + 2 * T * (q0 + q + 16))[0];
+                        h1[q] = (wt2 + 2 * T * (q0 + q + 16))[1];
+                    }
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int q = q0 + qq;
+                        const v2f a = v2f{xr0[q], xr1[q]} * v2f{l0[qq], l1[qq]}, xh = v2f{xr0[q + 16], xr1[q + 16]};
+                        const v2f wh = v2f{h0[qq], h1[qq]};
+                        v[2 * brev_c(q, 4)] = __builtin_elementwise_fma(xh, wh, a);
+                        v[2 * brev_c(q, 4) + 1] = __builtin_elementwise_fma(-xh, wh, a);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const v2f wl = __builtin_elementwise_fma(v2f{HANN_W14.s[q], HANN_W14.s[q]}, sb,
@@ -898,6 +945,22 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
         // ---- epilogue: synthesis window, overlap-add with the carried tail, store
         const v2f cbW = to_v(lds[T_H + 2 * tid]), sbW = to_v(lds[T_H + 2 * tid + 1]);
         const v2f half2k = {(float)(0.5 * HANN_KAPPA), (float)(0.5 * HANN_KAPPA)};
+        if constexpr (TABW) {
+            GF wt2 = per_hop(p.window) + lane2;
+            const v2f kap = half2k + half2k;  // -1/(4N)
+#pragma unroll
+            for (int q0 = 0; q0 < P; q0 += 4) {
+                float a0[4], a1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    a0[q] = (wt2 + 2 * T * (q0 + q))[0];
+                    a1[q] = (wt2 + 2 * T * (q0 + q))[1];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[q0 + q] *= v2f{a0[q], a1[q]} * kap;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < P; ++q)
             y[q] *= __builtin_elementwise_fma(v2f{HANN_W14K.s[q], HANN_W14K.s[q]}, sbW,
@@ -960,6 +1023,9 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
 
 }  // namespace
 
+#ifndef RC_HOP4_TABW
+#define RC_HOP4_TABW 1  // a caller's window at pitch 1 through hop4_kernel<1, false, true> (0: hop2_kernel, for A/B)
+#endif
 #ifndef RC_PITCHC
 #define RC_PITCHC 1  // pitch 2 and 3 run instantiations with the pitch at compile time (0: the runtime-pitch kernel, for A/B)
 #endif
@@ -988,8 +1054,13 @@ hipError_t launch_hop16k(const HopParams &p, hipStream_t s) {
         else if (p.pitch == 3 && RC_PITCHC) hipLaunchKernelGGL((hop4_kernel<3>), grid, block, lds4, s, p);
         else hipLaunchKernelGGL((hop4_kernel<0>), grid, block, lds4, s, p);
     } else {
+        if (!p.window || !p.env) return hipErrorInvalidValue;  // (the table-window kernels dereference both)
         const size_t lds2 = sizeof(float2) * (size_t)HOP2_LDS_FLOAT2;
-        if (p.pitch == 1) hipLaunchKernelGGL((hop2_kernel<true, false>), grid, block, lds2, s, p);
+        // pitch 1: hop4 with table windows (three workgroups per CU, run tickets, seams: hop_workgroups_per_cu says so
+        // to the planner); other pitches: hop2_kernel
+        if (p.pitch == 1 && RC_HOP4_TABW)
+            hipLaunchKernelGGL((hop4_kernel<1, false, true>), grid, block, sizeof(float2) * (size_t)HOP4_LDS_FLOAT2, s, p);
+        else if (p.pitch == 1) hipLaunchKernelGGL((hop2_kernel<true, false>), grid, block, lds2, s, p);
         else hipLaunchKernelGGL((hop2_kernel<false, false>), grid, block, lds2, s, p);
     }
     return hipGetLastError();

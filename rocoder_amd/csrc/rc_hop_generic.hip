@@ -471,8 +471,12 @@ hipError_t launch_hop_n(HopMode mode, const HopParams &p, hipStream_t s) {
 }
 }  // namespace
 
-int hop_workgroups_per_cu(int log2n, bool default_window) {
-    return (log2n == 14 && default_window) ? 3 : 0;  // hop4_kernel: three workgroups per CU
+#ifndef RC_HOP4_TABW
+#define RC_HOP4_TABW 1
+#endif
+int hop_workgroups_per_cu(int log2n, bool default_window, bool pitch1) {
+    // hop4_kernel: three workgroups per CU - the default window at any pitch, a caller's window at pitch 1 (round 5)
+    return (log2n == 14 && (default_window || (pitch1 && RC_HOP4_TABW))) ? 3 : 0;
 }
 
 int hop_slots(int log2n) {  // runs per workgroup of the fused generic kernel (hop_kernel: one wave holds 64 / T runs below N = 512)

@@ -164,7 +164,7 @@ constexpr uint32_t RC_DIAG_BIG4_64 = 8;
 bool hop_geometry(int log2n, int *threads, size_t *lds_bytes);
 // Workgroups of the fused kernel that share a CU when the kernel variant fixes it (0: derive it
 // from hop_geometry's LDS size). The run planner sizes a launch to two rounds of them.
-int hop_workgroups_per_cu(int log2n, bool default_window);
+int hop_workgroups_per_cu(int log2n, bool default_window, bool pitch1 = false);
 // Workgroups per CU of the wave-local kernels (rc_hopw.hip: N = 4096 / 8192 with the default window), 0 otherwise:
 // all runs are equally long, so the planner launches whole multiples of what is resident at once.
 int hop_resident_workgroups(int log2n, bool default_window);

@@ -168,7 +168,7 @@ bool hop_geometry(int log2n, int *threads, size_t *lds_bytes) {
     if (lds_bytes) *lds_bytes = sizeof(float2) * (size_t)(M + (M >> 5) + 1);
     return true;
 }
-int hop_workgroups_per_cu(int log2n, bool default_window) { return log2n == 14 ? (default_window ? 3 : 2) : 0; }
+int hop_workgroups_per_cu(int log2n, bool default_window, bool pitch1) { return log2n == 14 ? ((default_window || pitch1) ? 3 : 2) : 0; }
 int hop_resident_workgroups(int log2n, bool default_window) {
     if (!default_window) return 0;
     return log2n == 13 ? 6 : log2n == 12 ? 12 : (log2n >= 9 && log2n <= 11) ? 16 : 0;
