@@ -330,3 +330,21 @@ def test_kernel_id_is_a_hash_of_the_kernel_sources_and_current_profiles_match_it
         txt = open(os.path.join(ROOT, "profiles", name)).read()
         m = re.search(r"^#\s*kernel_id:\s*(\S+)", txt, re.M)
         assert m and m.group(1) == f"{fam}={have[fam]}", (fam, name, m and m.group(1), have[fam])
+
+
+def test_big5_index_model_closes():
+    """tests/dev/proto_big5.py models every exchange of big5_kernel (rc_big5.hip): which thread holds which element
+    after E1 ... E4 under the residue-class thread mapping, that the wave-local exchanges stay in their wave's region,
+    that everything fits eight regions of 2111 slots, and the bank conflicts of every wave instruction (none). The
+    kernel's index arithmetic was written from this model; the model stays green with it."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dev", "proto_big5.py")], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "all layouts check out" in r.stdout
+    worst = [int(ln.split(":")[-1]) for ln in r.stdout.splitlines() if "worst extra LDS cycles" in ln]
+    assert len(worst) == 12 and max(worst) == 0, r.stdout
