@@ -142,13 +142,30 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
         c.mem = (((c.a ^ (c.a >> 1)) & 1) << 4) | ((c.a & 2) ? k4 : wv);
         return c;
     };
-    for (int64_t k = (k_begin > 0 ? k_begin - 1 : k_begin); k < k_end; ++k) {
+    // (a 32-bit trip count: the scalar unit has no ordered 64-bit compare, so `k < k_end` on int64 ran on the VALU with
+    // k_end parked in a VGPR pair - this kernel's one scratch reload per hop)
+    const int64_t k_first = k_begin > 0 ? k_begin - 1 : k_begin;
+    const int n_it = (int)(k_end - k_first);
+    for (int it = 0; it < n_it; ++it) {
+        const int64_t k = k_first + it;
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         int tt = tid;  // per-hop opaque copy for the epilogue's addresses
         opaque(tt);
         v2f v[R];
         {   // register brev6(q) := z[q * T + t] * window, stage 0 inside the load loop (big4_kernel<64>'s pipeline)
-            GF src = hop_src(p, xc, xt, k);
+            // hop_src with `k >= tail_hop_first` as the sign of a 64-bit difference (k >= 0, tail_hop_first a hop index or
+            // INT64_MAX: no overflow): the scalar unit has no ordered 64-bit compare, the VALU form kept tail_hop_first in a
+            // VGPR pair that was parked in scratch and reloaded every hop
+            GF src;
+            {
+                const int dhi = __builtin_amdgcn_readfirstlane((int)((uint64_t)(k - p.tail_hop_first) >> 32));  // (opaque to the
+                const bool past = dhi >= 0;                       // optimiser, which would fold the sign test back into the compare)
+                const int64_t off = past ? (k * (int64_t)p.step - p.tail_origin) : (k * (int64_t)p.step - p.in_origin);
+                const unsigned long long sa = (unsigned long long)(past ? xt : xc) + (unsigned long long)off * 4ull;
+                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sa);
+                const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(sa >> 32));
+                src = (GF)(((unsigned long long)hi << 32) | lo);
+            }
             GF win = per_hop(p.window);
             v2f cbW = {0.f, 0.f}, sbW = cbW;
             if constexpr (HANN) {
