@@ -665,6 +665,8 @@ def worker(args, say):
             return
         state, err = None, None
         try:
+            if rehearsal and os.environ.get("ROCODER_BENCH_REHEARSAL_FAIL") == f"{name}:{rank}":
+                raise RuntimeError("rehearsal: injected set-up failure")  # (exercises the agreement below; dev only)
             with torch.cuda.stream(stream):
                 state = setup()
                 torch.cuda.synchronize(device)

@@ -155,3 +155,28 @@ def test_rccl_one_rank_walks_the_sharded_concat():
     assert res["backend"] == "nccl" and res["world"] == 1 and res["all_reduce"] == 3.5
     for k in ("broadcast_all", "root_only", "grouped_send_recv_to_self"):
         assert res[k] is True and res[k + "_into_caller_buffer"] is True, res
+
+
+@pytest.mark.gpu
+def test_bench_rehearsal_survives_a_leg_that_fails_on_one_rank():
+    """bench.py --gpus 2 without a launcher (it starts its own ranks), both ranks on this one GPU over gloo
+    (ROCODER_BENCH_REHEARSAL=1), with the set-up of the `weak` leg failing on rank 1 only: the ranks agree to skip that
+    leg's timed collectives (a rank that skipped its barriers alone hung the others), the main line is
+    printed with the error inside config.weak, the later legs still run, exit code 0."""
+    import json
+    import sys
+
+    env = dict(os.environ, ROCODER_BENCH_REHEARSAL="1", ROCODER_BENCH_REHEARSAL_FAIL="weak:1",
+               ROCODER_BENCH_CONCAT_TIMEOUT="150")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--preheat-s", "0.3"], env=env, capture_output=True, text=True, timeout=420)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["value"] > 0
+    cfg = res["config"]
+    assert "error" in cfg["weak"], cfg["weak"]
+    assert "ms_per_step_1gpu" in cfg["ref_1gpu"] and "ms_per_step" in cfg["c5_sharded"], cfg
+    assert "legs_error" not in cfg
