@@ -179,11 +179,16 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
             if constexpr (HANN) {
                 constexpr int PB = BIG4_PIPE_ROWS, NB = R / PB;
                 float xp0[2][PB], xp1[2][PB];
+                // buffer loads: the hop's base in a resource descriptor, ONE 32-bit lane offset for all rows, the row in the
+                // scalar offset - the global_load form spent 128 v_add_co / v_addc per hop on 64-bit lane addresses (hop4: -1 %)
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x40000000, 0x00020000);
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
                 auto issue = [&](int i, float (&x0)[PB], float (&x1)[PB]) {
 #pragma unroll
                     for (int q = 0; q < PB; ++q) {
-                        x0[q] = (src + 2 * T * ROW(i * PB + q))[lane2];
-                        x1[q] = (src + 2 * T * ROW(i * PB + q))[lane2 + 1];
+                        const v2u x = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(4u * lane2), 4 * 2 * T * ROW(i * PB + q), 0);
+                        x0[q] = __uint_as_float(x.x);
+                        x1[q] = __uint_as_float(x.y);
                     }
                 };
                 issue(0, xp0[0], xp1[0]);
@@ -543,6 +548,10 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
             const int64_t g0 = k * (int64_t)H;
             GFW dst = outc + (g0 / (int64_t)pitch - p.out_origin);
             const uint32_t kr = (uint32_t)(g0 % pitch);
+            const unsigned long long da = (unsigned long long)dst;  // (uniform: descriptor in SGPRs)
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+                (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(da >> 32)) << 32) |
+                         (unsigned)__builtin_amdgcn_readfirstlane((int)da)), 0, 0x40000000, 0x00020000);
             constexpr int EB = (HANN && PITCH1) ? BIG4_EPI_BATCH : 4;
 #pragma unroll
             for (int q0 = 0; q0 < PH; q0 += EB) {
@@ -587,7 +596,9 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
                         // stretcher.rs:97-100; with the computed envelope the amplitude is already inside it
                         const v2f o = HANN ? (head + tq[q]) * v2f{e0[q], e1[q]} : (head + tq[q]) * v2f{e0[q], e1[q]} * ampk;
                         if constexpr (PITCH1) {
-                            __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * (q0 + q) + lane2));
+                            typedef unsigned v2u __attribute__((ext_vector_type(2)));  // (buffer store, aux 2 = nt, as the loads)
+                            __builtin_amdgcn_raw_buffer_store_b64(v2u{__float_as_uint(o.x), __float_as_uint(o.y)}, rd,
+                                                                  (int)(4u * lane2), 4 * 2 * T * (q0 + q), 2);
                         } else {
                             const uint32_t a0 = kr + 2u * (uint32_t)(tid + T * (q0 + q)), a1 = a0 + 1;
                             const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;

@@ -2,6 +2,9 @@
 // bench.py measures) and hop2_kernel's table variant (caller-supplied window). DESIGN.md 5.1b / 5.1d.
 #include "rc_dit.hpp"
 
+#ifndef RC_HOP4_BUFLOAD
+#define RC_HOP4_BUFLOAD 1  // hop4's input rows through buffer loads (0: global loads with 64-bit lane addresses, for A/B)
+#endif
 namespace rc {
 namespace {
 
@@ -571,6 +574,14 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);  // (the builtin returns int:
             const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));  // widen as unsigned)
             GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
+#if RC_HOP4_BUFLOAD
+            // (buffer stores like the input loads: descriptor + one lane offset + the row in the scalar offset; aux 2 = nt)
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, 0x40000000, 0x00020000);
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#define HOP4_STORE(o, row) __builtin_amdgcn_raw_buffer_store_b64(v2u{__float_as_uint((o).x), __float_as_uint((o).y)}, rd, (int)(4u * lane2), 4 * 2 * T * (row), 2)
+#else
+#define HOP4_STORE(o, row) __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * (row) + lane2))
+#endif
             if constexpr (TABW) {
                 GF et2 = per_hop(p.env) + lane2;
 #pragma unroll
@@ -584,7 +595,7 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const v2f o = (head[q0 + q] + tail[q0 + q]) * v2f{e0[q], e1[q]} * amp2;  // stretcher.rs:97-100
-                        __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * (q0 + q) + lane2));
+                        HOP4_STORE(o, q0 + q);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -596,7 +607,7 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
                                __builtin_elementwise_fma(v2f{HANN_E14.c[q], HANN_E14.c[q]}, cbE, halfa));
                 const v2f o = (head[q] + tail[q]) * er;  // (y + tail) * (env * amp), stretcher.rs:97-100
                 // non-temporal: the output is written once; the window overlap of consecutive hops stays in the XCD's L2
-                __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * q + lane2));
+                HOP4_STORE(o, q);
             }
         } else {
             const int64_t kq = g0 / pitch;
@@ -665,11 +676,26 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
         {   // register brev5(q) := z[q * T + t] * window ; F1 = stages 0..4
             GF src = hop_src(p, xc, xt, k);
             float xr0[P], xr1[P];
+#if RC_HOP4_BUFLOAD
+            {   // buffer loads: the hop's base in a resource descriptor (SGPRs), ONE 32-bit lane offset for all rows, the row
+                // in the scalar offset - no 64-bit VALU address arithmetic (the global_load form spent 2 x 16 v_add_co /
+                // v_addc per hop and wave on it, with an address pair live per two rows)
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x40000000, 0x00020000);
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    const v2u x = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(4u * lane2), 4 * 2 * T * q, 0);
+                    xr0[q] = __uint_as_float(x.x);
+                    xr1[q] = __uint_as_float(x.y);
+                }
+            }
+#else
 #pragma unroll
             for (int q = 0; q < P; ++q) {
                 xr0[q] = (src + 2 * T * q)[lane2];
                 xr1[q] = (src + 2 * T * q)[lane2 + 1];
             }
+#endif
             const v2f cb = to_v(lds[T_H + 2 * tid]), sb = to_v(lds[T_H + 2 * tid + 1]);
             // stage 0 pairs registers brev5(q) and brev5(q + 16) = brev5(q) + 1: a +- b with a = x_q w_q and
             // b = x_{q+16} w_{q+16} is one multiply and two FMAs
