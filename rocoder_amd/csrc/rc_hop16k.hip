@@ -574,14 +574,16 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
             const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)da);  // (the builtin returns int:
             const unsigned dhi = __builtin_amdgcn_readfirstlane((unsigned)(da >> 32));  // widen as unsigned)
             GFW dst = (GFW)(((unsigned long long)dhi << 32) | dlo);
-#if RC_HOP4_BUFLOAD
             // (buffer stores like the input loads: descriptor + one lane offset + the row in the scalar offset; aux 2 = nt)
             const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, 0x40000000, 0x00020000);
             typedef unsigned v2u __attribute__((ext_vector_type(2)));
-#define HOP4_STORE(o, row) __builtin_amdgcn_raw_buffer_store_b64(v2u{__float_as_uint((o).x), __float_as_uint((o).y)}, rd, (int)(4u * lane2), 4 * 2 * T * (row), 2)
-#else
-#define HOP4_STORE(o, row) __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * (row) + lane2))
-#endif
+#define HOP4_STORE(o, row)                                                                                                  \
+    do {                                                                                                                    \
+        if constexpr (RC_HOP4_BUFLOAD && !TABW)                                                                             \
+            __builtin_amdgcn_raw_buffer_store_b64(v2u{__float_as_uint((o).x), __float_as_uint((o).y)}, rd,                 \
+                                                  (int)(4u * lane2), 4 * 2 * T * (row), 2);                                 \
+        else __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * (row) + lane2));                                           \
+    } while (0)
             if constexpr (TABW) {
                 GF et2 = per_hop(p.env) + lane2;
 #pragma unroll
@@ -676,10 +678,11 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
         {   // register brev5(q) := z[q * T + t] * window ; F1 = stages 0..4
             GF src = hop_src(p, xc, xt, k);
             float xr0[P], xr1[P];
-#if RC_HOP4_BUFLOAD
-            {   // buffer loads: the hop's base in a resource descriptor (SGPRs), ONE 32-bit lane offset for all rows, the row
+            if constexpr (RC_HOP4_BUFLOAD && !TABW) {
+                // buffer loads: the hop's base in a resource descriptor (SGPRs), ONE 32-bit lane offset for all rows, the row
                 // in the scalar offset - no 64-bit VALU address arithmetic (the global_load form spent 2 x 16 v_add_co /
-                // v_addc per hop and wave on it, with an address pair live per two rows)
+                // v_addc per hop and wave on it, with an address pair live per two rows). Not in the table-window
+                // instantiation: there the allocator spills 10 more dwords with them and the kernel is 7 % slower
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x40000000, 0x00020000);
                 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -688,14 +691,13 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
                     xr0[q] = __uint_as_float(x.x);
                     xr1[q] = __uint_as_float(x.y);
                 }
-            }
-#else
+            } else {
 #pragma unroll
-            for (int q = 0; q < P; ++q) {
-                xr0[q] = (src + 2 * T * q)[lane2];
-                xr1[q] = (src + 2 * T * q)[lane2 + 1];
+                for (int q = 0; q < P; ++q) {
+                    xr0[q] = (src + 2 * T * q)[lane2];
+                    xr1[q] = (src + 2 * T * q)[lane2 + 1];
+                }
             }
-#endif
             const v2f cb = to_v(lds[T_H + 2 * tid]), sb = to_v(lds[T_H + 2 * tid + 1]);
             // stage 0 pairs registers brev5(q) and brev5(q + 16) = brev5(q) + 1: a +- b with a = x_q w_q and
             // b = x_{q+16} w_{q+16} is one multiply and two FMAs

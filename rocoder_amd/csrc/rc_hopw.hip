@@ -124,8 +124,22 @@ __device__ __forceinline__ void wfence() {
 // F1: register brev5(q) := z[q * T + t] * window, stages 0..4. Stage 0 pairs registers brev5(q) and brev5(q + 16) =
 // brev5(q) + 1: a +- b with a = x_q w_q and b = x_{q+16} w_{q+16} is one multiply and two FMAs
 // the hop's samples: row q of thread t = samples 2 T q + 2 t, + 1
-template <int T, int P>
+// UNIFORM: `src` is the same for every lane (one hop per wave / per two waves): raw buffer loads - the hop's base in a
+// resource descriptor, one 32-bit lane offset for all rows, the row in the scalar offset (round 5, as hop4_kernel:
+// no 64-bit VALU address arithmetic). The two-hops-per-wave kernels pass per-lane pointers and keep global loads.
+template <int T, int P, bool UNIFORM = false>
 __device__ __forceinline__ void hopw_load(GF src, unsigned lane2, float (&xr0)[P], float (&xr1)[P]) {
+    if constexpr (UNIFORM) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x40000000, 0x00020000);
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const v2u x = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(4u * lane2), 4 * 2 * T * q, 0);
+            xr0[q] = __uint_as_float(x.x);
+            xr1[q] = __uint_as_float(x.y);
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < P; ++q) {
         xr0[q] = (src + 2 * T * q)[lane2];
@@ -181,7 +195,7 @@ __device__ __forceinline__ void hopw_f1x(const float (&xr0)[P], const float (&xr
 template <int T, int m, int P = 32, bool TABW = false>
 __device__ __forceinline__ void hopw_f1(GF src, unsigned lane2, v2f cb, v2f sb, const HannK32 &W, v2f (&v)[P], GF wt2 = nullptr) {
     float xr0[P], xr1[P];
-    hopw_load<T, P>(src, lane2, xr0, xr1);
+    hopw_load<T, P, true>(src, lane2, xr0, xr1);  // (hopw_f1's callers pass hop_src: uniform)
     hopw_f1x<T, m, P, TABW>(xr0, xr1, cb, sb, W, v, wt2);
 }
 
@@ -621,7 +635,7 @@ __global__ __launch_bounds__(64, RC_HOPW11_WPS) void hopw11_kernel(const HopPara
     // stores' round trips (timing-only build without stores: -8 %)
     float xr0[P], xr1[P];
     const int64_t k_first = k_begin > 0 ? k_begin - 1 : k_begin;
-    hopw_load<T, P>(hop_src(p, xc, xt, k_first), lane2, xr0, xr1);
+    hopw_load<T, P, true>(hop_src(p, xc, xt, k_first), lane2, xr0, xr1);
     for (int64_t k = k_first; k < k_end; ++k) {
         const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
         v2f v[P];
@@ -734,7 +748,7 @@ __global__ __launch_bounds__(64, RC_HOPW11_WPS) void hopw11_kernel(const HopPara
                 wfence();
             }
         }
-        if (RC_HOPW_PREFETCH) hopw_load<T, P>(hop_src(p, xc, xt, k + 1 < k_end ? k + 1 : k), lane2, xr0, xr1);
+        if (RC_HOPW_PREFETCH) hopw_load<T, P, true>(hop_src(p, xc, xt, k + 1 < k_end ? k + 1 : k), lane2, xr0, xr1);
         dit_stages<16, m, 6, 9, 6, true, true>(y, to_v(lds[H1_TA + lane()]));
         {
             const int t = lane();
@@ -743,7 +757,7 @@ __global__ __launch_bounds__(64, RC_HOPW11_WPS) void hopw11_kernel(const HopPara
                                         (float)(0.5 * HANN_KAPPA11), pitch, TABW ? per_hop(p.window) + 2 * t : nullptr,
                                         TABW ? per_hop(p.env) + 2 * t : nullptr);
         }
-        if (!RC_HOPW_PREFETCH) hopw_load<T, P>(hop_src(p, xc, xt, k + 1 < k_end ? k + 1 : k), lane2, xr0, xr1);
+        if (!RC_HOPW_PREFETCH) hopw_load<T, P, true>(hop_src(p, xc, xt, k + 1 < k_end ? k + 1 : k), lane2, xr0, xr1);
     }
 }
 
