@@ -800,7 +800,8 @@ def e2e_host(eng, x, torch):
     upload, compute and output download as one pipelined call. Three forms of the same job, median of 3 calls each:
       pinned           rows from rc_host_alloc on both sides (DMA straight from / into the caller's memory)
       pageable_reused  ordinary numpy arrays, the output array allocated once and reused (its pages exist)
-      pageable_fresh   a new output array per call (np.empty inside the call: every page is faulted in on the way)"""
+      pageable_fresh   a new output array per call (np.empty inside the call: every page is faulted in on the way; the
+                       previous result is released before the clock starts)"""
     import numpy as np
 
     import rocoder_amd
@@ -835,8 +836,16 @@ def e2e_host(eng, x, torch):
         t = med(lambda: eng.stretch_host(xh, out=yh))
         r["pageable_reused_Msamples_s"] = round(total / t / 1e6, 1)
         del yh
-        t = med(lambda: eng.stretch_host(xh), reps=2)
-        r["pageable_fresh_Msamples_s"] = round(total / t / 1e6, 1)
+        # a new output array per call; the previous one is released BEFORE the clock starts (unmapping 1.7 GB of touched
+        # pages costs tens of milliseconds and is not part of the call)
+        ts, keep = [], eng.stretch_host(xh)
+        for _ in range(2):
+            keep = None
+            t0 = time.perf_counter()
+            keep = eng.stretch_host(xh)
+            ts.append(time.perf_counter() - t0)
+        del keep
+        r["pageable_fresh_Msamples_s"] = round(total / statistics.median(ts) / 1e6, 1)
     except Exception as ex:  # noqa: BLE001
         r["pageable_error"] = f"{type(ex).__name__}: {ex}"[:200]
     return r
