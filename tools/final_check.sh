@@ -1,0 +1,10 @@
+#!/bin/bash
+# One gpurun call that re-checks a tree: the whole GPU suite, smoke(), the default bench line.
+#   gpurun --timeout 1200 -- 'bash tools/final_check.sh'   -> gpurun_out/final_*.log, final_bench.json
+# (tools/gpu_steps.sh: a step that times out or faults on the GPU ends the sequence and fails the script)
+source tools/gpu_steps.sh
+step 1100 final_tests_gpu python -m pytest tests -q -x -m gpu
+step 300 final_smoke python __graft_entry__.py smoke
+step 400 final_bench python bench.py
+grep -h '^{' gpurun_out/final_bench.log > gpurun_out/final_bench.json
+finish
