@@ -957,11 +957,13 @@ def test_16384_full_length_every_sample_vs_oracle(p):
     assert_blocks(got, ref, H, f"full length p={p}")
 
 
-@pytest.mark.parametrize("case", ["table_window_pitch3", "three_channels"])
+@pytest.mark.parametrize("case", ["table_window_pitch3", "three_channels", "table_window_pitch1"])
 def test_16384_full_length_other_kernel_paths(case):
     """The same every-sample check on the paths the default-window stereo job does not take: (a) C3's geometry
     (pitch 3) with a caller-supplied window - hop2_kernel's table variant, decimating stores included; (b) three
-    channels at L >= 3 M - an odd channel count through hop4's per-XCD run tickets and seam hand-overs."""
+    channels at L >= 3 M - an odd channel count through hop4's per-XCD run tickets and seam hand-overs; (c) a
+    caller-supplied window at pitch 1 - hop4_kernel's table-window instantiation (round 5) through ~370 runs, seam
+    hand-overs included."""
     import torch
 
     ra = _engine_mod()
@@ -969,6 +971,10 @@ def test_16384_full_length_other_kernel_paths(case):
     if case == "table_window_pitch3":
         ch, L, p = 2, 1_200_000, 3
         w = (oc.hanning(N).astype(np.float64) ** 1.5).astype(np.float32)  # not the default window: table path
+        kw = dict(window=w)
+    elif case == "table_window_pitch1":
+        ch, L, p = 2, 1_700_000, 1
+        w = (oc.hanning(N).astype(np.float64) ** 1.5).astype(np.float32)
         kw = dict(window=w)
     else:
         ch, L, p = 3, 3_000_000, 1
