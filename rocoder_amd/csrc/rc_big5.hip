@@ -622,6 +622,339 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
 #endif
 }
 
+
+// ======================= N = 32768: the same scheme with single-round exchanges ==========================
+// big4_kernel<32>'s arithmetic (M = 16384 points, 32 per thread: F1 stages 0..4, F2 5..9, F3 10..13 on two sets of 16,
+// I1 0..3, I2 4..8, I3 9..13) under big5's thread mapping: a wave is a residue class, E2 and E3 run inside the wave
+// without barriers in its own region. Every exchange moves all 32 registers at once, so the cross-wave ones cannot have
+// a writer-major AND a reader-major round; E1 is writer-major (own region, no barrier at its entry: the region was last
+// read by the wave itself in E4), E4 reader-major (a wave reads its own region: the next hop's E1 needs no entry
+// barrier): store / BAR / load / BAR and BAR / store / BAR / load - four barriers per hop instead of big4's eight.
+// The index maps are big5's round-0 (E1), wave-local (E2, E3: gp = register bit 4) and round-1 (E4) maps.
+constexpr int big5s_lds_float2() { return BIG5_XBUF + 512 + 1; }
+template <bool PITCH1, bool HANN>
+__global__ __launch_bounds__(BIG5_T, 2) void big5s_kernel(const HopParams p) {
+    constexpr int R = 32, b = 5, m = 14, LOG2N = 15, M = 1 << m, H = M, T = BIG5_T;
+    constexpr int RES = 1024, PH = R / 2, RG = BIG5_REGION;
+    constexpr int T_A = BIG5_XBUF, SCR = T_A + 512;
+    extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    const int tid = threadIdx.x;
+    const uint32_t run = blockIdx.x % p.runs_per_channel;
+    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
+    int64_t k_end = k_begin + p.run_len;
+    if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
+    if (k_begin >= k_end) return;
+    GF xc = (GF)p.x + (size_t)ch * p.in_stride;
+    GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
+    GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
+    const unsigned lane2 = 2u * (unsigned)tid;
+    const uint32_t pitch = PITCH1 ? 1u : p.pitch;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave = residue class
+    {
+        GV2 wt = (GV2)p.wtab;  // exp(-2 pi i k / M)
+        GV2 rt = (GV2)p.rtab;  // exp(-2 pi i j / N)
+        lds[T_A + tid] = ldg2(wt + tid);
+        if (tid == 0) {  // W_N^(RES/2 - M/2) = i W_N^(RES/2): thread 0's twiddle base for its second residue
+            const float2 wq = ldg2(rt + RES / 2);
+            lds[SCR] = make_float2(-wq.y, wq.x);
+        }
+        __syncthreads();
+    }
+    v2f tail[PH];
+#pragma unroll
+    for (int q = 0; q < PH; ++q) tail[q] = v2f{0.f, 0.f};
+    const bool is0 = tid == 0;
+    struct Cls {
+        int lane, a, low4, mem;
+    };
+    auto cls = [&]() {
+        const int t = tid;
+        Cls c;
+        c.lane = t & 63;
+        c.a = c.lane >> 4;
+        c.low4 = c.lane & 15;
+        const int k4 = wv ? 16 - wv : 8;
+        c.mem = (((c.a ^ (c.a >> 1)) & 1) << 4) | ((c.a & 2) ? k4 : wv);
+        return c;
+    };
+    const Cls c = cls();                       // (R = 32 has the registers: the identities stay live across the hop)
+    const int tau = c.mem | (c.low4 << 5);     // F3 / I1: this thread's residues are tau and RES - tau
+    auto set_base = [&](int s, int skew) {     // region base of set s (0: tau, 1: its partner) for the E2 loads / E3 stores
+        const int an = wv ? (c.a ^ 2) : (c.a < 2 ? c.a : (c.a ^ 1));
+        const int y = c.low4;
+        // (thread 0: the partner of residue 0 is RES / 2 = 512, bits 5..9 = 16 - at N = 65536 it is 1024 = 0 mod 1024)
+        const int ye = s ? (is0 ? 16 : (c.mem ? 31 - y : ((32 - y) & 31))) : y;
+        const int ae = s ? an : c.a;
+        return RG * wv + 16 * (ae & 1) + 528 * ((ae >> 1) | ((ye >> 4) << 1)) + skew * (ye & 15);
+    };
+    const int64_t k_first = k_begin > 0 ? k_begin - 1 : k_begin;
+    const int n_it = (int)(k_end - k_first);
+    for (int it = 0; it < n_it; ++it) {
+        const int64_t k = k_first + it;
+        const PhaseKey key = make_phase_key(p.seed_mixed, p.ch_first + ch, k);
+        v2f v[R];
+        {   // register brev5(q) := z[q * T + t] * window, stage 0 inside the fold
+            GF src = hop_src(p, xc, xt, k);
+            GF win = per_hop(p.window);
+            v2f cbW = {0.f, 0.f}, sbW = cbW;
+            if constexpr (HANN) {
+                GV2 hr = (GV2)per_hop(p.hann_rot) + 2 * tid;
+                const float2 a0 = ldg2(hr), a1 = ldg2(hr + 1);
+                cbW = v2f{a0.x, a1.x};
+                sbW = v2f{a0.y, a1.y};
+            }
+            const HannK64 &HW = HANN_W15;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x40000000, 0x00020000);
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#define ROW(i) (((i) >> 1) + ((i) & 1) * (R / 2))
+            constexpr int LB = HANN ? R : 16;
+#pragma unroll
+            for (int q0 = 0; q0 < R; q0 += LB) {
+                float xr0[LB], xr1[LB], wr0[HANN ? 1 : LB], wr1[HANN ? 1 : LB];
+#pragma unroll
+                for (int q = 0; q < LB; ++q) {
+                    const v2u x = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(4u * lane2), 4 * 2 * T * ROW(q0 + q), 0);
+                    xr0[q] = __uint_as_float(x.x);
+                    xr1[q] = __uint_as_float(x.y);
+                    if constexpr (!HANN) {
+                        wr0[q] = (win + 2 * T * ROW(q0 + q))[lane2];
+                        wr1[q] = (win + 2 * T * ROW(q0 + q))[lane2 + 1];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < LB; q += 2) {
+                    v2f w0, w1;
+                    if constexpr (HANN) {
+                        const int r0 = ROW(q0 + q), r1 = ROW(q0 + q + 1);
+                        w0 = __builtin_elementwise_fma(v2f{HW.s[r0], HW.s[r0]}, sbW,
+                             __builtin_elementwise_fma(v2f{HW.c[r0], HW.c[r0]}, cbW, v2f{0.5f, 0.5f}));
+                        w1 = __builtin_elementwise_fma(v2f{HW.s[r1], HW.s[r1]}, sbW,
+                             __builtin_elementwise_fma(v2f{HW.c[r1], HW.c[r1]}, cbW, v2f{0.5f, 0.5f}));
+                    } else {
+                        w0 = v2f{wr0[q], wr1[q]};
+                        w1 = v2f{wr0[q + 1], wr1[q + 1]};
+                    }
+                    const v2f a = v2f{xr0[q], xr1[q]} * w0, xh = v2f{xr0[q + 1], xr1[q + 1]};
+                    v[brev_c(ROW(q0 + q), b)] = __builtin_elementwise_fma(xh, w1, a);
+                    v[brev_c(ROW(q0 + q), b) + 1] = __builtin_elementwise_fma(-xh, w1, a);
+                }
+            }
+#undef ROW
+            dit_g<R, 1, b - 1, 0, false, false>(v);
+        }
+        // ---- E1: F1 -> F2 (cross-wave, writer-major). Element P: P0..4 = register q, P5..13 = brev9(tid)
+        v2f w[R];
+        {
+            const int bs = (int)(__brev((unsigned)tid) >> 23);  // brev9(t): bit i = P(5 + i)
+            const int w0b = RG * wv + (bs >> 5) + (((bs >> 3) & 3) << 9);
+            const int r0b = c.low4 + 16 * ((c.mem >> 4) | ((c.mem & 15) << 1));
+#pragma unroll
+            for (int q = 0; q < 32; ++q) lds[w0b + 16 * ((q >> 4) | ((q & 15) << 1))] = to_f2(v[q]);
+            BIG5_BAR();
+#pragma unroll
+            for (int j = 0; j < 32; ++j) w[j] = to_v(lds[r0b + RG * brev_c(j & 7, 3) + 512 * (j >> 3)]);
+            BIG5_BAR();  // (every wave has read every region: E2 may overwrite the own one)
+        }
+        dit_g<32, b, b + 4, b, false, true>(w, to_v(lds[T_A + 16 * c.mem]));
+        // ---- E2: F2 -> F3 inside the wave: x + 16 (a & 1) + 33 uu + 528 ((a >> 1) | gp << 1), y = j = x | gp << 4
+        v2f va[16], vb[16];
+        const float2 wrl = ldg2((GV2)per_hop(reinterpret_cast<const float *>(p.rtab)) + tau);  // W_N^tau, for the pair stage
+        {
+            const int e2w = RG * wv + 16 * (c.a & 1) + 528 * (c.a >> 1) + 33 * c.low4;
+            BIG5_FENCE();
+#pragma unroll
+            for (int j = 0; j < 32; ++j) lds[e2w + (j & 15) + 1056 * (j >> 4)] = to_f2(w[j]);
+            BIG5_FENCE();
+            const int ra = set_base(0, 1), rb = set_base(1, 1);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                va[q] = to_v(lds[ra + 33 * q]);
+                vb[q] = to_v(lds[rb + 33 * q]);
+            }
+        }
+        // ---- F3, the pair stage in registers, I1 (big4_kernel's, with r = tau)
+        {
+            const int r = tau;
+            {
+                const v2f wa = to_v(lds[T_A + r]);  // W_M^r
+                const v2f k16 = {W32_RE[2], W32_IM[2]};
+                v2f wb = vcmul(v2f{wa.x, -wa.y}, k16);  // W_M^(RES - r) = W_16 conj(W_M^r)
+                if (is0) wb = v2f{W32_RE[1], W32_IM[1]};  // thread 0: residue RES/2 -> W_32
+                dit_g<16, b + 5, b + 8, b + 5, false, true>(va, wa);
+                dit_g<16, b + 5, b + 8, b + 5, false, true>(vb, wb);
+            }
+            const bool sp = is0;
+            v2f s8 = va[8];
+            if (wv == 0) {
+                const v2f va0 = va[0];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const v2f a = va[8 + i], b0 = vb[i], b1 = vb[8 + i];
+                    const v2f nx = i < 7 ? va[9 + i] : va0;
+                    va[8 + i] = vsel(sp, b0, a);
+                    vb[i] = vsel(sp, b1, b0);
+                    vb[8 + i] = vsel(sp, nx, b1);
+                }
+            }
+            {
+                const float2 w0 = lds[SCR];
+                const float2 wrh = make_float2(sp ? w0.x : wrl.x, sp ? w0.y : wrl.y);
+                const uint32_t x0 = (uint32_t)r * key.mul + key.k0;
+                const uint32_t dx = (uint32_t)RES * key.mul;
+                const uint32_t x0h = x0 - (sp ? (uint32_t)(M / 2 - RES / 2) * key.mul : 0u);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float2 wr = q < 8 ? wrl : wrh;
+                    const v2f wrv = to_v(wr);
+                    const v2f wq = q == 0 ? wrv : (q == 8 ? v2f{wr.y, -wr.x}
+                                   : vcmul(wrv, v2f{W32_RE[q & 15], W32_IM[q & 15]}));
+                    v2f VA, VB;
+                    if (q == 0)
+                        pair_regs_pk4<LOG2N, true>(va[q], vb[15 - q], wq, x0, key, VA, VB, sp);
+                    else
+                        pair_regs_pk4<LOG2N>(va[q], vb[15 - q], wq, (q < 8 ? x0 : x0h) + (uint32_t)q * dx, key, VA, VB);
+                    va[q] = VA;
+                    vb[15 - q] = VB;
+                }
+            }
+            if (wv == 0) {  // bin M/2 pairs with itself; un-deal thread 0's registers
+                v2f V8, V8b;
+                pair_regs_pk4<LOG2N>(s8, s8, v2f{0.0f, -1.0f}, 8u * (uint32_t)RES * key.mul + key.k0, key, V8, V8b);
+                v2f na[8], nb0[8], nb1[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    na[i] = vsel(sp, i == 0 ? V8 : vb[7 + i], va[8 + i]);
+                    nb0[i] = vsel(sp, va[8 + i], vb[i]);
+                    nb1[i] = vsel(sp, vb[i], vb[8 + i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    va[8 + i] = na[i];
+                    vb[i] = nb0[i];
+                    vb[8 + i] = nb1[i];
+                }
+            }
+            v2f pa[16], pb[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                pa[brev_c(q, 4)] = va[q];
+                pb[brev_c(q, 4)] = vb[q];
+            }
+            dit_g<16, 0, 3, 0, true, false>(pa);
+            dit_g<16, 0, 3, 0, true, false>(pb);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                va[q] = pa[q];
+                vb[q] = pb[q];
+            }
+        }
+        // ---- E3: I1 -> I2 inside the wave: q' + 16 (a & 1) + 33 x + 528 ((a >> 1) | gp << 1); I2 register j = P'4..8 holds
+        // the residue bits 9..5: y = brev5(j)
+        {
+            const int wa_ = set_base(0, 33), wb_ = set_base(1, 33);
+            const int e3r = RG * wv + c.low4 + 16 * (c.a & 1) + 528 * (c.a >> 1);
+            BIG5_FENCE();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                lds[wa_ + q] = to_f2(va[q]);
+                lds[wb_ + q] = to_f2(vb[q]);
+            }
+            BIG5_FENCE();
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int y = brev_c(j, 5);
+                v[j] = to_v(lds[e3r + 33 * (y & 15) + 1056 * (y >> 4)]);
+            }
+        }
+        dit_g<32, 4, 8, 4, true, true>(v, to_v(lds[T_A + c.low4 * R]));  // I2: stages 4..8, base W_512^l4 = W_M^(32 l4)
+        // ---- E4: I2 -> I3 (cross-wave, reader-major): element l4 | j << 4 | brev5(member) << 9 goes to the region of the
+        // wave that reads it (P'6..8 = (j >> 2) & 7) at P'0..5 | (P'9..13) << 6
+        v2f y[R];
+        {
+            const int bm = (int)(__brev((unsigned)c.mem) >> 27);
+            const int w1b = c.low4 + 64 * bm;
+            BIG5_BAR();  // (the other waves are done with their regions: their E3 is behind them)
+#pragma unroll
+            for (int j = 0; j < 32; ++j) lds[w1b + RG * (j >> 2) + 16 * (j & 3)] = to_f2(v[j]);
+            BIG5_BAR();
+#pragma unroll
+            for (int q = 0; q < 32; ++q) y[q] = to_v(lds[RG * wv + (tid & 63) + 64 * q]);
+        }
+        dit_g<R, 9, m - 1, 9, true, true>(y, to_v(lds[T_A + tid]));  // I3: stages 9..13
+        // ---- epilogue: synthesis window, overlap-add, store (big4_kernel<32>'s)
+        {
+            GF win = per_hop(p.window);
+            GF esrc = per_hop(p.env);
+            v2f cbW = {0.f, 0.f}, sbW = cbW, cbE = cbW, sbE = cbW;
+            if constexpr (HANN) {
+                GV2 hr = (GV2)per_hop(p.hann_rot) + 2 * tid;
+                const float2 a0 = ldg2(hr), a1 = ldg2(hr + 1), e0r = ldg2(hr + 2 * T), e1r = ldg2(hr + 2 * T + 1);
+                cbW = v2f{a0.x, a1.x};
+                sbW = v2f{a0.y, a1.y};
+                cbE = v2f{e0r.x, e1r.x};
+                sbE = v2f{e0r.y, e1r.y};
+            }
+            const HannK64 &HW = HANN_W15;
+            const HannK64 &HE = HANN_E15;
+            const v2f hf = {0.5f, 0.5f};
+            const float ak = p.amp * (-0.25f / (float)(1 << LOG2N));  // pair_regs_pk4 leaves the -1/(4N) out
+            const v2f ampk = {ak, ak};
+            v2f hfE = hf;
+            if constexpr (HANN) {
+                cbE *= ampk;
+                sbE *= ampk;
+                hfE = hf * ampk;
+            }
+            const int64_t g0 = k * (int64_t)H;
+            GFW dst = outc + (g0 / (int64_t)pitch - p.out_origin);
+            const uint32_t kr = (uint32_t)(g0 % pitch);
+            constexpr int EB = 8;
+#pragma unroll
+            for (int q0 = 0; q0 < PH; q0 += EB) {
+                float wr0[EB], wr1[EB], wt0[EB], wt1[EB], e0[EB], e1[EB];
+#pragma unroll
+                for (int q = 0; q < EB; ++q) {
+                    if constexpr (!HANN) {
+                        wr0[q] = (win + 2 * T * (q0 + q))[lane2];
+                        wr1[q] = (win + 2 * T * (q0 + q))[lane2 + 1];
+                        wt0[q] = (win + 2 * T * (q0 + q + PH))[lane2];
+                        wt1[q] = (win + 2 * T * (q0 + q + PH))[lane2 + 1];
+                        e0[q] = (esrc + 2 * T * (q0 + q))[lane2];
+                        e1[q] = (esrc + 2 * T * (q0 + q))[lane2 + 1];
+                    } else {
+                        const v2f wh = __builtin_elementwise_fma(v2f{HW.s[q0 + q], HW.s[q0 + q]}, sbW,
+                                       __builtin_elementwise_fma(v2f{HW.c[q0 + q], HW.c[q0 + q]}, cbW, hf));
+                        const v2f wt = __builtin_elementwise_fma(v2f{HW.s[q0 + q + PH], HW.s[q0 + q + PH]}, sbW,
+                                       __builtin_elementwise_fma(v2f{HW.c[q0 + q + PH], HW.c[q0 + q + PH]}, cbW, hf));
+                        const v2f ev = __builtin_elementwise_fma(v2f{HE.s[q0 + q], HE.s[q0 + q]}, sbE,
+                                       __builtin_elementwise_fma(v2f{HE.c[q0 + q], HE.c[q0 + q]}, cbE, hfE));
+                        wr0[q] = wh.x, wr1[q] = wh.y, wt0[q] = wt.x, wt1[q] = wt.y, e0[q] = ev.x, e1[q] = ev.y;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < EB; ++q) {
+                    const v2f head = y[q0 + q] * v2f{wr0[q], wr1[q]};
+                    const v2f nt = y[q0 + q + PH] * v2f{wt0[q], wt1[q]};
+                    if (k >= k_begin) {
+                        const v2f o = HANN ? (head + tail[q0 + q]) * v2f{e0[q], e1[q]}
+                                           : (head + tail[q0 + q]) * v2f{e0[q], e1[q]} * ampk;  // stretcher.rs:97-100
+                        if constexpr (PITCH1) {
+                            __builtin_nontemporal_store(o, (GV2W)(dst + 2 * T * (q0 + q) + lane2));
+                        } else {
+                            const uint32_t a0 = kr + 2u * (uint32_t)(tid + T * (q0 + q)), a1 = a0 + 1;
+                            const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
+                            if (d0 * pitch == a0) dst[d0] = o.x;
+                            if (d1 * pitch == a1) dst[d1] = o.y;
+                        }
+                    }
+                    tail[q0 + q] = nt;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 size_t big5_lds_bytes() { return sizeof(float2) * (size_t)big5_lds_float2(); }
@@ -633,6 +966,17 @@ hipError_t launch_big5(const HopParams &p, hipStream_t s) {
     else if (p.pitch == 1) hipLaunchKernelGGL((big5_kernel<true, false>), grid, block, lds, s, p);
     else if (hann) hipLaunchKernelGGL((big5_kernel<false, true>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((big5_kernel<false, false>), grid, block, lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_big5s(const HopParams &p, hipStream_t s) {
+    const dim3 grid(p.runs_per_channel * p.n_channels), block(BIG5_T);
+    const size_t lds = sizeof(float2) * (size_t)big5s_lds_float2();
+    const bool hann = p.hann_rot != nullptr;
+    if (p.pitch == 1 && hann) hipLaunchKernelGGL((big5s_kernel<true, true>), grid, block, lds, s, p);
+    else if (p.pitch == 1) hipLaunchKernelGGL((big5s_kernel<true, false>), grid, block, lds, s, p);
+    else if (hann) hipLaunchKernelGGL((big5s_kernel<false, true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((big5s_kernel<false, false>), grid, block, lds, s, p);
     return hipGetLastError();
 }
 

@@ -216,6 +216,8 @@ hipError_t launch_big_cr(const BigOlaParams &p, hipStream_t s);
 hipError_t launch_big4(int log2n, const HopParams &p, hipStream_t s);
 // N = 65536 (BASELINE C5): big4_kernel<64>'s arithmetic with wave-local E2 / E3 exchanges (rc_big5.hip); same HopParams
 hipError_t launch_big5(const HopParams &p, hipStream_t s);
+// N = 32768: the same thread mapping with single-round exchanges (big5s_kernel), four barriers per hop instead of eight
+hipError_t launch_big5s(const HopParams &p, hipStream_t s);
 size_t big5_lds_bytes();
 // floats of per-workgroup tail scratch (HopParams::ybuf) big4_kernel needs per run for this window length: 0 when
 // the carried tail y_{k-1}[H..] lives in registers (the default build, both lengths)

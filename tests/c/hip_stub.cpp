@@ -193,6 +193,7 @@ hipError_t launch_big(int, const BigParams &, hipStream_t, HopMode) { return hip
 hipError_t launch_big_cr(const BigOlaParams &, hipStream_t) { return hipSuccess; }
 hipError_t launch_big4(int, const HopParams &, hipStream_t) { return hipSuccess; }
 hipError_t launch_big5(const HopParams &, hipStream_t) { return hipSuccess; }
+hipError_t launch_big5s(const HopParams &, hipStream_t) { return hipSuccess; }
 size_t big5_lds_bytes() { return 0; }
 size_t big4_tail_scratch_floats(int) { return 0; }
 hipError_t launch_dev_kernel(const DevKernelParams &, hipStream_t) { return hipSuccess; }

@@ -245,8 +245,104 @@ def run():
     return lds.worst
 
 
+def run32():
+    """big5s_kernel (N = 32768, 32 points per thread): single-round exchanges with big5's maps - E1 writer-major (round 0's
+    map on a 14-bit position: P0..4 = register, P5..13 = brev9(tid)), E2 / E3 wave-local (y = the five residue bits 5..9 =
+    the F2 register), E4 reader-major (round 1's map)."""
+    RES32 = 1024
+    lds = Lds()
+    waves = [list(range(w * 64, w * 64 + 64)) for w in range(8)]
+
+    def e1(P):   # uu = P10..13, Y = P4 | P0..3 << 1 | P8 << 5 | P9 << 6
+        return ((P >> 10) & 15) | ((((P >> 4) & 1) | (P & 15) << 1 | ((P >> 8) & 3) << 5) << 4)
+
+    F1 = {t: [brev(t, 9) << 5 | q for q in range(32)] for t in range(T)}
+    F2 = {t: [None] * 32 for t in range(T)}
+    for w, wv in enumerate(waves):
+        for q in range(32):
+            ad = []
+            for t in wv:
+                P = F1[t][q]
+                assert brev((P >> 5) & 7, 3) == w
+                ad.append(REGION * w + e1(P))
+            lds.access("E1.st", "w", ad, [F1[t][q] for t in wv])
+    for k, wv in enumerate(waves):
+        for j in range(32):
+            ad = []
+            for t in wv:
+                lane = t & 63
+                P = member(k, lane >> 4) | j << 5 | (lane & 15) << 10
+                ad.append(REGION * brev(j & 7, 3) + e1(P))
+            got = lds.access("E1.ld", "r", ad)
+            for t, x in zip(wv, got):
+                F2[t][j] = x
+    for k, wv in enumerate(waves):
+        for t in wv:
+            lane = t & 63
+            for j in range(32):
+                assert F2[t][j] == (member(k, lane >> 4) | j << 5 | (lane & 15) << 10)
+    tau_of = {t: member(t >> 6, (t & 63) >> 4) | (t & 15) << 5 for t in range(T)}
+    assert sorted(tau_of.values()) == list(range(512))
+
+    def res32(tau):
+        return [tau, (RES32 // 2 if tau == 0 else RES32 - tau)]
+
+    F3 = {t: [[None] * 16 for _ in range(2)] for t in range(T)}
+    for k, wv in enumerate(waves):
+        for j in range(32):
+            ad = [REGION * k + e2(member(k, (t & 63) >> 4) | j << 5, t & 15) for t in wv]
+            lds.access("E2.st", "w", ad, [F2[t][j] for t in wv])
+        for s_ in range(2):
+            for q in range(16):
+                ad = [REGION * k + e2(res32(tau_of[t])[s_] & 1023, q) for t in wv]
+                got = lds.access("E2.ld", "r", ad)
+                for t, x in zip(wv, got):
+                    F3[t][s_][q] = x
+    for t in range(T):
+        for s_, r in enumerate(res32(tau_of[t])):
+            for q in range(16):
+                assert F3[t][s_][q] == ((r & 1023) | q << 10), ("F3", t, s_, q)   # (residue 512 <-> RES/2 for tau = 0 handled by & 1023)
+    I1 = {t: [[qq | brev(r & 1023, 10) << 4 for qq in range(16)] for r in res32(tau_of[t])] for t in range(T)}
+    I2 = {t: [None] * 32 for t in range(T)}
+    for k, wv in enumerate(waves):
+        for s_ in range(2):
+            for qq in range(16):
+                ad = [REGION * k + e3(res32(tau_of[t])[s_] & 1023, qq) for t in wv]
+                lds.access("E3.st", "w", ad, [I1[t][s_][qq] for t in wv])
+        for j in range(32):
+            ad = []
+            for t in wv:
+                lane = t & 63
+                ad.append(REGION * k + e3(member(k, lane >> 4) | brev(j, 5) << 5, lane & 15))
+            got = lds.access("E3.ld", "r", ad)
+            for t, x in zip(wv, got):
+                I2[t][j] = x
+    for k, wv in enumerate(waves):
+        for t in wv:
+            lane = t & 63
+            for j in range(32):
+                assert I2[t][j] == ((lane & 15) | j << 4 | brev(member(k, lane >> 4), 5) << 9), ("I2", t, j)
+    I3 = {t: [None] * 32 for t in range(T)}
+    for k, wv in enumerate(waves):
+        for j in range(32):
+            ad = [REGION * ((I2[t][j] >> 6) & 7) + ((I2[t][j] & 63) | (I2[t][j] >> 9) << 6) for t in wv]
+            lds.access("E4.st", "w", ad, [I2[t][j] for t in wv])
+    for w, wv in enumerate(waves):
+        for q in range(32):
+            got = lds.access("E4.ld", "r", [REGION * w + ((t & 63) | q << 6) for t in wv])
+            for t, x in zip(wv, got):
+                I3[t][q] = x
+    for t in range(T):
+        for q in range(32):
+            assert I3[t][q] == (t | q << 9), ("I3", t, q)
+    return lds.worst
+
+
 if __name__ == "__main__":
     worst = run()
     for k in sorted(worst):
         print(f"  {k:10s} worst extra LDS cycles per lane group: {worst[k]}")
+    worst32 = run32()
+    for k in sorted(worst32):
+        print(f"  R32 {k:6s} worst extra LDS cycles per lane group: {worst32[k]}")
     print("all layouts check out")

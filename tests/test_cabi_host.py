@@ -347,4 +347,4 @@ def test_big5_index_model_closes():
     assert r.returncode == 0, r.stderr[-2000:]
     assert "all layouts check out" in r.stdout
     worst = [int(ln.split(":")[-1]) for ln in r.stdout.splitlines() if "worst extra LDS cycles" in ln]
-    assert len(worst) == 12 and max(worst) == 0, r.stdout
+    assert len(worst) == 20 and max(worst) == 0, r.stdout  # 12 wave instructions of big5_kernel, 8 of big5s_kernel

@@ -1448,18 +1448,21 @@ def test_pitch_multiple_i8_corners_match_oracle(N, L, f, p, ch):
         assert_parity(got[c], ref[c], f"N={N} f={f} p={p} ch={c}", reg=4.0e-6)
 
 
-@pytest.mark.parametrize("ch,L,table_window,p", [(3, 700_000, False, 1), (1, 300_000, True, 1), (2, 500_000, False, 3)])
-def test_big5_agrees_with_big4_at_window_65536(monkeypatch, ch, L, table_window, p):
+@pytest.mark.parametrize("N,ch,L,table_window,p", [(65536, 3, 700_000, False, 1), (65536, 1, 300_000, True, 1),
+                                                   (65536, 2, 500_000, False, 3), (32768, 3, 500_000, False, 1),
+                                                   (32768, 2, 300_000, True, 2), (32768, 1, 20_000, False, 1)])
+def test_big5_agrees_with_big4_at_window_65536(monkeypatch, N, ch, L, table_window, p):
     """N = 65536: big5_kernel (round 5: wave-local E2 / E3 exchanges, six barriers per hop) against round 4's
     big4_kernel<64> (ROCODER_DIAG=8 in the test-hook library). Same butterflies, twiddles and pair stage element for
     element except the inverse stage 9, whose twiddle now comes from the table instead of four squarings: agreement
-    far inside the oracle gate, on the computed default window, a caller's window and a decimating store."""
+    far inside the oracle gate, on the computed default window, a caller's window and a decimating store.
+    N = 32768: big5s_kernel (the same thread mapping with single-round exchanges, four barriers) against big4_kernel<32>."""
     import torch
 
     ra = _engine_mod()
     from rocoder_amd import _lib
 
-    N, f, seed = 65536, 16.0, 0x5EED
+    f, seed = 16.0, 0x5EED
     x = np.stack([onp.synth_input(c, L) for c in range(ch)])
     xt = torch.from_numpy(x).cuda()
     kw = dict(window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=seed)

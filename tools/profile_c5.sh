@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel stats of BASELINE C5 on one GPU (tools/bench_c5.py: fused big5_kernel; the window-32768 twin: big4_kernel<32>) -> gpurun_out/<tag>/
+# rocprofv3 kernel stats of BASELINE C5 on one GPU (tools/bench_c5.py: fused big5_kernel; the window-32768 twin: big5s_kernel) -> gpurun_out/<tag>/
 set -u
 TAG=$1
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
@@ -22,9 +22,9 @@ out, tag = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "big4" in r["Kernel_Name"] or "big5" in r["Kernel_Name"]:  # (N = 65536 runs big5_kernel since round 5)
-            key = ("R64 (N=65536)" if "big5" in r["Kernel_Name"] or "Li64E" in r["Kernel_Name"] or "<64" in r["Kernel_Name"]
-                   else "R32 (N=32768)")
+        if "big4" in r["Kernel_Name"] or "big5" in r["Kernel_Name"]:  # (round 5: N = 65536 runs big5_kernel, N = 32768 big5s_kernel)
+            key = ("R32 (N=32768)" if "big5s" in r["Kernel_Name"] or "<32" in r["Kernel_Name"] or "Li32E" in r["Kernel_Name"]
+                   else "R64 (N=65536)")
             acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(f"{out}/{tag}_pmc_summary.txt", "w") as g:
     try:  # the family id of the kernels these counters belong to (rc_kernel_id(): a hash of the big4 sources)
@@ -40,7 +40,7 @@ with open(f"{out}/{tag}_pmc_summary.txt", "w") as g:
         g.write(f"# this box, same call, un-profiled: C5 {b['N65536']['ms_median']} ms, window-32768 twin {b['N32768']['ms_median']} ms ({tag}_bench.json)\n")
     except Exception as e:  # noqa: BLE001
         g.write(f"# (no bench line: {e})\n")
-    g.write("# big5_kernel (N = 65536) and big4_kernel<32> (N = 32768), tools/bench_c5.py (8 ch x 5 292 000, factor 32), mean per launch, separate --pmc passes\n")
+    g.write("# big5_kernel (N = 65536) and big5s_kernel (N = 32768), tools/bench_c5.py (8 ch x 5 292 000, factor 32), mean per launch, separate --pmc passes\n")
     for key in sorted(acc):
         g.write(f"## {key}\n")
         for k in sorted(acc[key]):
