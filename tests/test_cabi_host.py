@@ -205,9 +205,13 @@ _RUST_SCALARS = {"u8": (1, 1), "i8": (1, 1), "u16": (2, 2), "i16": (2, 2), "u32"
                  "c_char": (1, 1), "RcFreqKernel": (8, 8)}  # Option<extern "C" fn> is pointer-sized (null = None)
 
 
+RUST_DIR = os.path.join(ROOT, "integration", "rust")
+
+
 def _rust_blocks():
-    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    rust = "\n".join(re.findall(r"```rust\n(.*?)```", text, flags=re.S))
+    """The reference-side binding ships as files (integration/rust/*.rs; INTEGRATION.md names them): the FFI
+    declarations are hip_engine.rs."""
+    rust = open(os.path.join(RUST_DIR, "hip_engine.rs")).read()
     return re.sub(r"//[^\n]*", "", rust)
 
 
@@ -215,7 +219,7 @@ def _rust_struct_layout(rust, name):
     """repr(C): fields in declaration order, each at the next multiple of its alignment; size rounded up to the
     largest alignment (x86-64 / aarch64 LP64: pointers and usize are 8 bytes)."""
     m = re.search(r"#\[repr\(C\)\]\s*pub struct %s\s*\{(.*?)\}" % name, rust, flags=re.S)
-    assert m, f"no #[repr(C)] struct {name} in INTEGRATION.md"
+    assert m, f"no #[repr(C)] struct {name} in integration/rust/hip_engine.rs"
     off, max_al, out = 0, 1, {}
     for fname, ty in re.findall(r"pub\s+(\w+)\s*:\s*([^,}]+?)\s*(?:,|$)", m.group(1).strip() + ","):
         ty = ty.strip()
@@ -270,7 +274,8 @@ def _header_prototypes():
 
 
 def test_integration_md_rust_stub_matches_the_header():
-    """the reference-side binding cannot be compiled here (no rustc), but
+    """the reference-side binding (integration/rust/hip_engine.rs, the file
+    INTEGRATION.md section 1 tells a maintainer to copy) cannot be compiled here (no rustc), but
     its text can be held to the C side: (a) the #[repr(C)] structs, laid out by the repr(C) rules, reproduce the table
     the C compiler printed (tests/golden/abi_layout.json); (b) the extern "C" block declares exactly the functions of
     include/rocoder_hip.h, with the header's argument and return types."""
@@ -300,6 +305,61 @@ def test_integration_md_rust_stub_matches_the_header():
     assert sorted(protos) == _header_functions()
     for name in protos:
         assert fns[name] == protos[name], (name, fns[name], protos[name])
+
+
+def test_rust_integration_files_are_consistent_with_each_other_and_with_integration_md():
+    """What else can be held without rustc: INTEGRATION.md names exactly the files that exist; the ABI version and the
+    constants hip_engine.rs declares are the header's; every rc_* function the other Rust files call is declared in
+    hip_engine.rs's extern block with that many arguments; the trampoline's exported symbol has the rc_freq_kernel
+    shape and is the symbol the dispatcher resolves; braces and parentheses balance in every file; and no file holds
+    text of the reference's sources (new code only)."""
+    files = sorted(f for f in os.listdir(RUST_DIR) if f.endswith(".rs"))
+    assert files == ["build.rs", "hip_engine.rs", "kernel_trampoline.rs", "stretcher_hip.rs"]
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for f in files:
+        assert f"integration/rust/{f}" in md, f
+    assert "```rust" not in md, "Rust lives in integration/rust/, INTEGRATION.md refers to it"
+    h = open(os.path.join(ROOT, "include", "rocoder_hip.h")).read()
+    abi = int(re.search(r"#define RC_ABI_VERSION (\d+)", h).group(1))
+    assert abi == _lib.lib().rc_abi_version()
+    assert re.search(r"rc_abi_version\(\)`? (?:is|returns) %d\b" % abi, md), "INTEGRATION.md quotes another ABI version"
+    eng = open(os.path.join(RUST_DIR, "hip_engine.rs")).read()
+    assert re.search(r"pub const RC_ABI_VERSION: c_int = %d;" % abi, eng)
+    for name in ("RC_OK", "RC_WOULD_BLOCK", "RC_DK_NONE", "RC_DK_GAIN", "RC_DK_BAND", "RC_DK_SHIFT"):
+        c_val = int(re.search(r"#define %s \(?(-?\d+)\)?" % name, h).group(1))
+        r_val = int(re.search(r"pub const %s: \w+ = (-?\d+);" % name, eng).group(1))
+        assert c_val == r_val, name
+    protos = _header_prototypes()
+    for f in files:
+        src = open(os.path.join(RUST_DIR, f)).read()
+        code = re.sub(r"//[^\n]*", "", src)
+        code_ns = re.sub(r'r#".*?"#', '""', code, flags=re.S)  # (raw strings hold Rust text of their own)
+        for o, c in ("{}", "()", "[]"):
+            assert code_ns.count(o) == code_ns.count(c), (f, o)
+        if f == "hip_engine.rs":
+            continue
+        for name, args in re.findall(r"\b(rc_\w+)\(((?:[^()]|\([^()]*\))*)\)", code_ns):
+            if name == "rc_apply":
+                continue
+            assert name in protos, (f, name)
+            depth, n_args = 0, 1 if args.strip() else 0
+            for ch in args:
+                depth += ch in "([{"
+                depth -= ch in ")]}"
+                n_args += ch == "," and depth == 0
+            assert n_args == len(protos[name][1]), (f, name, args)
+        # new code only: none of the reference's own identifiers that the replacement makes obsolete
+        for gone in ("SliceDeque", "rustfft", "FftPlanner", "thread_rng", "amp_correction_envelope"):
+            assert gone not in code_ns, (f, gone)
+    tr = open(os.path.join(RUST_DIR, "kernel_trampoline.rs")).read()
+    m = re.search(r'pub unsafe extern "C" fn rc_apply\((.*?)\)\s*->\s*i32', tr, flags=re.S)
+    assert m
+    got = [a.split(":", 1)[1].strip() for a in " ".join(m.group(1).split()).split(",")]
+    assert got == ["u64", "*const f32", "*mut f32", "usize", "*mut std::ffi::c_void"]
+    assert 'b"rc_apply\\0"' in tr  # the dispatcher resolves the symbol the trampoline exports
+    m = re.search(r'pub unsafe extern "C" fn dispatch\((.*?)\)\s*->\s*c_int', tr, flags=re.S)
+    got = [a.split(":")[1].strip() for a in " ".join(m.group(1).split()).split(",")]
+    assert got == ["u64", "*const f32", "*mut f32", "usize", "*mut c_void"]  # = RcFreqKernel
 
 
 def test_kernel_id_is_a_hash_of_the_kernel_sources_and_current_profiles_match_it():
