@@ -221,6 +221,37 @@ def spawn_ranks(args, argv):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+
+    def kill_all(sig=signal.SIGKILL):
+        """Exactly the process groups started below (each rank is the leader of its own session)."""
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    # ADVICE r5: the ranks live in their own sessions, so a SIGTERM / SIGINT / SIGHUP that reaches only this launcher
+    # (an outer `timeout`, gpurun's limit, Ctrl-C) must be passed on - otherwise GPU-initialised ranks are orphaned
+    # inside a collective. The launcher never touches the GPU, so handling signals here is safe.
+    class _Stopped(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        kill_all()
+        raise _Stopped(signum)
+
+    previous = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
+
+    def die_with_parent():
+        # a SIGKILLed launcher runs no handler: the kernel then signals the rank itself (PR_SET_PDEATHSIG = 1)
+        try:
+            import ctypes
+
+            ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)
+        except Exception:  # noqa: BLE001  (best effort; the handlers above cover the ordinary cases)
+            pass
+
     for r in range(args.gpus):
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -229,7 +260,7 @@ def spawn_ranks(args, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(),
-                                      start_new_session=True))
+                                      start_new_session=True, preexec_fn=die_with_parent))
     limit = float(os.environ.get("ROCODER_BENCH_SPAWN_TIMEOUT", "1500"))
     t_end = time.monotonic() + limit
     out = b""
@@ -249,12 +280,7 @@ def spawn_ranks(args, argv):
             if (deadline is not None and now > deadline) or now > t_end:
                 if rc == 0:
                     rc = 124
-                for p in procs:
-                    if p.poll() is None:
-                        try:
-                            os.killpg(p.pid, signal.SIGKILL)
-                        except ProcessLookupError:
-                            pass
+                kill_all()
                 break
             time.sleep(0.1)
         for p in procs:
@@ -265,9 +291,26 @@ def spawn_ranks(args, argv):
     import threading
 
     reaper = threading.Thread(target=reap, args=(30.0,), daemon=True)
-    reaper.start()
-    out = procs[0].stdout.read()  # ends when rank 0 exits (or is killed by the reaper)
-    reaper.join()
+    stopped = None
+    try:
+        reaper.start()
+        out = procs[0].stdout.read()  # ends when rank 0 exits (or is killed by the reaper)
+        reaper.join()
+    except _Stopped as ex:
+        stopped = int(ex.args[0])
+    finally:
+        kill_all()  # whatever ended the wait (a signal, KeyboardInterrupt, an error): no rank outlives the launcher
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+        for sg, h in previous.items():
+            signal.signal(sg, h)
+    if stopped is not None:
+        print(json.dumps(error_line(args, f"launcher stopped by signal {stopped}; its {args.gpus} ranks were killed")),
+              flush=True)
+        return 128 + stopped
     line = None
     for ln in out.decode(errors="replace").splitlines():
         if ln.startswith("{"):
@@ -295,6 +338,12 @@ def main():
         return 2
     if args.gpus > 1 and "RANK" not in os.environ:
         return spawn_ranks(args, sys.argv[1:])  # torch not imported, GPU not touched in this process
+    if "RANK" in os.environ and os.environ.get("ROCODER_BENCH_TEST_RANK_PIDDIR"):
+        # test hook (tests/test_bench_host.py): a rank that only records its pid and waits - what a rank stuck in a
+        # collective looks like to the launcher - so the launcher's signal handling can be tested without a GPU
+        open(os.path.join(os.environ["ROCODER_BENCH_TEST_RANK_PIDDIR"], os.environ["RANK"]), "w").write(str(os.getpid()))
+        time.sleep(600)
+        return 0
 
     # Exactly ONE line on stdout (the JSON): RCCL / the HIP runtime print banners to fd 1, so park
     # the real stdout and point fd 1 at stderr until the result is ready.
