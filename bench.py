@@ -553,6 +553,8 @@ def worker(args, say):
             extras["e2e_pcie"] = e2e_host(eng, x, torch)
             extras["other_configs"] = other_configs(torch, device, dev_index, stream, x, threading, kernel_ids)
             extras["shard_sizes"] = shard_sizes(torch, device, stream, eng, x, wout, nwin)
+            extras["c5_share"] = c5_share(torch, device, dev_index, stream)
+            extras["seam"] = seam_numbers()
 
     res = None
     if rank == 0:
@@ -669,6 +671,11 @@ def worker(args, say):
             res["config"]["shard_sizes_on_one_gpu"] = extras["shard_sizes"]
         if "other_configs" in extras:  # not the metric's config: BASELINE configs[2..4] on this one GPU
             res["config"]["other_configs"] = extras["other_configs"]
+        if "c5_share" in extras:
+            res["config"]["c5_share_on_one_gpu"] = extras["c5_share"]
+        if "seam" in extras:
+            res["config"]["streaming_seam"] = extras["seam"].get("streaming_seam")
+            res["config"]["live_latency_us"] = extras["seam"].get("live_latency_us")
         if world == 1 and not args.no_cpu_baseline:
             one, many = cpu_baselines()
             res["cpu_baseline"] = one
@@ -933,6 +940,111 @@ def shard_sizes(torch, device, stream, eng, x, wout, nwin):
                 del bufs
     except Exception as ex:  # noqa: BLE001
         out["error"] = f"{type(ex).__name__}: {ex}"[:300]
+    return out
+
+
+def c5_share(torch, device, dev_index, stream):
+    """BASELINE configs[4] is DEFINED as an 8-GPU job (8 channels, window 65536, factor 32, one channel per GPU): what one
+    rank of it costs, measured on this one GPU - rank 0's shard of shard_plan(8 channels, n windows, 8 ranks) = one whole
+    channel (5 106 hops over the 256 one-per-CU workgroups of big5_kernel), through the launch `bench.py --gpus 8` issues
+    per rank (config.c5_sharded). NOT a multi-GPU measurement (the data path has no collective)."""
+    import rocoder_amd
+    from rocoder_amd.distributed import engine_compute, shard_plan
+
+    out = {}
+    try:
+        with torch.cuda.stream(stream):
+            x5 = synth_on_device(torch, device, 8, 5_292_000)
+            e5 = rocoder_amd.Engine(window_len=65536, factor=32.0, sample_rate=SAMPLE_RATE, channels=8, seed=SEED, device=dev_index)
+            wout5, nwin5 = e5.params.window_out_len, e5.output_len(x5.shape[1]) // e5.params.window_out_len
+            comp = engine_compute(e5, x5)
+            whole = torch.empty((8, nwin5 * wout5), dtype=torch.float32, device=device)
+            for _ in range(3):
+                e5.stretch_tensor(x5, out=whole)
+            stream.synchronize()
+            for _ in range(12):
+                e5.stretch_tensor(x5, out=whole)
+            stream.synchronize()
+            whole_ms = statistics.median(e5.kernel_times(10))
+            del whole
+            mine = [sh for sh in shard_plan(8, nwin5, 8) if sh.rank == 0]
+            bufs = {sh: torch.empty((sh.ch_count, sh.win_count * wout5), dtype=torch.float32, device=device) for sh in mine}
+            for _ in range(20):
+                for sh in mine:
+                    comp(sh, out=bufs[sh])
+            stream.synchronize()
+            k = 100
+            t = time.perf_counter()
+            for _ in range(k):
+                for sh in mine:
+                    comp(sh, out=bufs[sh])
+            stream.synchronize()
+            wall = (time.perf_counter() - t) / k
+            kms = statistics.median(e5.kernel_times(32))
+            hops = sum(sh.ch_count * sh.win_count for sh in mine) * e5.params.hops_per_window
+            out = {"shards_of_rank0": [(sh.ch_first, sh.ch_count, sh.win_first, sh.win_count) for sh in mine],
+                   "hops": hops, "kernel_ms": round(kms, 4), "step_wall_ms": round(wall * 1e3, 4),
+                   "frac_hbm_read": round(hops * 4.0 * 65536 / kms / 1e6 / HBM_PEAK_GBS, 4),
+                   "whole_job_kernel_ms_on_this_gpu": round(whole_ms, 4),
+                   "percent_of_linear": round(100.0 * whole_ms / 8.0 / kms, 1),
+                   "job_Msamples_s_if_all_ranks_alike": round(float(nwin5) * wout5 * 8 / wall / 1e6, 1)}
+            e5.close()
+            del bufs, x5
+    except Exception as ex:  # noqa: BLE001
+        out["error"] = f"{type(ex).__name__}: {ex}"[:300]
+    return out
+
+
+def seam_numbers():
+    """The literal drop-in seam (rc_engine_push_input / close_input / next_window(_view): what INTEGRATION.md tells a
+    maintainer to bind), driven from C in the processor's order (tools/seam_bench.c, built by build() into
+    rocoder_amd/bin/libseam_bench.so) on the engine library this process has loaded:
+      streaming_seam  - the C2 job as a CLOSED stereo job (`-o` mode), output samples/s of the hand-out loop with the
+                        copying call and with the pointer-returning one; host buffers, PCIe inside (never `value`);
+      live_latency_us - OPEN channels (live mode), window 16384, stereo: each round pushes the input one output window
+                        consumes to every channel and asks every channel for its window; first = until the first
+                        next_window returns, round = until all have; --buffer 1 s and 0.1 s."""
+    import ctypes as C
+
+    from rocoder_amd import _lib
+
+    out = {}
+    try:
+        so = os.path.join(ROOT, "rocoder_amd", "bin", "libseam_bench.so")
+        sb = C.CDLL(so)
+        sb.seam_bench_closed.argtypes = [C.c_char_p, C.c_uint32, C.c_float, C.c_uint32, C.c_size_t, C.c_int,
+                                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        sb.seam_bench_live.argtypes = [C.c_char_p, C.c_uint32, C.c_float, C.c_uint32, C.c_float, C.c_uint32,
+                                       C.POINTER(C.c_double)]
+        lib = _lib.LIB_PATH.encode()
+        seam = {}
+        for name, view in (("copy", 0), ("view", 1)):
+            best, push = 0.0, 0.0
+            for _ in range(2):
+                sps, pms, n = C.c_double(0), C.c_double(0), C.c_uint64(0)
+                rc = sb.seam_bench_closed(lib, WINDOW, FACTOR, CHANNELS, L_IN, view, C.byref(sps), C.byref(pms), C.byref(n))
+                if rc != 0:
+                    raise RuntimeError(f"seam_bench_closed({name}) returned {rc}")
+                if sps.value > best:
+                    best, push = sps.value, pms.value
+            seam[f"{name}_Msamples_s"] = round(best / 1e6, 1)
+            seam[f"{name}_push_ms"] = round(push, 1)
+        seam["job"] = f"closed stereo job, L={L_IN}/ch, window {WINDOW}, factor {FACTOR:g}; round-robin over the channels; best of 2"
+        out["streaming_seam"] = seam
+        live = {}
+        for buf in (1.0, 0.1):
+            o = (C.c_double * 6)()
+            rc = sb.seam_bench_live(lib, WINDOW, FACTOR, CHANNELS, buf, 1000, o)
+            if rc != 0:
+                raise RuntimeError(f"seam_bench_live({buf}) returned {rc}")
+            live[f"buffer_{buf:g}s"] = {"first_window_median": round(o[0], 1), "first_window_p99": round(o[1], 1),
+                                       "first_window_mean": round(o[2], 1), "first_window_max": round(o[3], 1),
+                                       "round_median": round(o[4], 1), "round_p99": round(o[5], 1)}
+        live["what"] = ("open stereo channels, window 16384, factor 8: push of one window's input advance (2048 samples) per "
+                        "channel -> rc_engine_next_window returns; 1000 rounds after 8 untimed ones")
+        out["live_latency_us"] = live
+    except Exception as ex:  # noqa: BLE001
+        out.setdefault("streaming_seam", {})["error"] = f"{type(ex).__name__}: {ex}"[:300]
     return out
 
 

@@ -216,6 +216,15 @@ __device__ __forceinline__ void phase_ncs2_x(uint32_t x, float &lo_nc, float &lo
     up_nc = __builtin_amdgcn_cosf(fu);
     up_ns = __builtin_amdgcn_sinf(fu);
 }
+// The same two draws as HALF-angle operands for the folded pair stage (pair_regs_pk5, rc_dit.hpp): with r = theta / 2 pi,
+//   g_lo = 0.25 + r(c) / 2        (the 23-bit draw under the exponent of [0.25, 0.5): exact)
+//   g_up = 0.5  + r(c + M)        (the 16-bit draw under the exponent of [0.5, 1), as phase_rev_upper)
+// so that fma(g_up, +-0.5, +-g_lo) is 0.5 + (r_lo + r_up) / 2 and (r_lo - r_up) / 2 in one instruction each.
+__device__ __forceinline__ void phase_g2_x(uint32_t x, float &g_lo, float &g_up) {
+    const uint32_t h = phase_hash_x(x);
+    g_lo = __uint_as_float(0x3E800000u | (h >> 9));
+    g_up = phase_rev_upper(h);
+}
 // the four phases of the pair (ja, M - ja), ja < M: bins ja, N - ja, M - ja, M + ja from the two
 // hashes of counters ja and M - ja. ja == 0 wraps: N - 0 is bin 0 again and M - 0 is bin M.
 __device__ __forceinline__ void phase_quad(PhaseKey k, uint32_t ja, uint32_t M, float &c1, float &s1,

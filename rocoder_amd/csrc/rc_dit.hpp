@@ -85,6 +85,43 @@ __device__ __forceinline__ void vdit_i(v2f a, v2f b, v2f &r, v2f &o) {
     r = CONJ ? m : p;
     o = CONJ ? p : m;
 }
+// Two runtime-twiddle butterflies as ONE asm block, their three packed FMAs interleaved (t0 t1 r0 r1 o0 o1): no
+// v_pk_fma_f32 is followed by its consumer (hipcc pads every such pair around an inline asm with an s_nop, and a
+// dependent packed FMA issues 8 cycles after its producer: a lone wave runs the one-butterfly form at half rate).
+// In place: r lands in b's registers, o in a's; ROT0 / ROT1: that butterfly's twiddle is -i w (CONJ: +i conj w).
+#ifndef RC_BF2
+#define RC_BF2 1
+#endif
+#define RC_BF_T_N "op_sel_hi:[1,0,1]"
+#define RC_BF_T_R "op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+#define RC_BF_R_N "op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]"
+#define RC_BF_R_NC "op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+#define RC_BF_R_R "op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]"
+#define RC_BF_R_RC "op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[0,1,0]"
+#define RC_BF2_ASM(T0, R0, T1, R1)                                                                           \
+    asm("v_pk_fma_f32 %[t0], %[b0], %[w0], %[a0] " T0 "\n\t"                                                 \
+        "v_pk_fma_f32 %[t1], %[b1], %[w1], %[a1] " T1 "\n\t"                                                 \
+        "v_pk_fma_f32 %[b0], %[b0], %[w0], %[t0] " R0 "\n\t"                                                 \
+        "v_pk_fma_f32 %[b1], %[b1], %[w1], %[t1] " R1 "\n\t"                                                 \
+        "v_pk_fma_f32 %[a0], %[a0], 2.0, %[b0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"          \
+        "v_pk_fma_f32 %[a1], %[a1], 2.0, %[b1] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"              \
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [a0] "+v"(a0), [b0] "+v"(b0), [a1] "+v"(a1), [b1] "+v"(b1)         \
+        : [w0] "v"(w0), [w1] "v"(w1))
+template <bool CONJ>
+__device__ __forceinline__ void vdit2_m(v2f &a0, v2f &b0, v2f w0, bool rot0, v2f &a1, v2f &b1, v2f w1, bool rot1) {
+    v2f t0, t1;
+    if (CONJ) {
+        if (!rot0 && !rot1) RC_BF2_ASM(RC_BF_T_N, RC_BF_R_NC, RC_BF_T_N, RC_BF_R_NC);
+        else if (!rot0) RC_BF2_ASM(RC_BF_T_N, RC_BF_R_NC, RC_BF_T_R, RC_BF_R_RC);
+        else if (!rot1) RC_BF2_ASM(RC_BF_T_R, RC_BF_R_RC, RC_BF_T_N, RC_BF_R_NC);
+        else RC_BF2_ASM(RC_BF_T_R, RC_BF_R_RC, RC_BF_T_R, RC_BF_R_RC);
+    } else {
+        if (!rot0 && !rot1) RC_BF2_ASM(RC_BF_T_N, RC_BF_R_N, RC_BF_T_N, RC_BF_R_N);
+        else if (!rot0) RC_BF2_ASM(RC_BF_T_N, RC_BF_R_N, RC_BF_T_R, RC_BF_R_R);
+        else if (!rot1) RC_BF2_ASM(RC_BF_T_R, RC_BF_R_R, RC_BF_T_N, RC_BF_R_N);
+        else RC_BF2_ASM(RC_BF_T_R, RC_BF_R_R, RC_BF_T_R, RC_BF_R_R);
+    }
+}
 template <int NREG, int M_LOG, int S_LO, int S_HI, int REG_LO, bool CONJ, bool HAS_L>
 __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], v2f wfine = v2f{1.0f, 0.0f}) {
     const v2f sgn = CONJ ? v2f{1.0f, -1.0f} : v2f{-1.0f, 1.0f};
@@ -138,6 +175,17 @@ __device__ __forceinline__ void dit_stages(v2f (&v)[NREG], v2f wfine = v2f{1.0f,
                     twr[c] = __builtin_shufflevector(tw[c], tw[c], 0, 0) * (-sgn);
                 }
             }
+            if (RC_BF2 && RC_ASMNEG) {
+                // butterfly i of the stage: q0 = the i-th register index with bit rb clear
+#pragma unroll
+                for (int i = 0; i < NREG / 2; i += 2) {
+                    const int qa = ((i >> rb) << (rb + 1)) | (i & (half - 1)), qb = (((i + 1) >> rb) << (rb + 1)) | ((i + 1) & (half - 1));
+                    const int ca_ = qa & (half - 1), cb_ = qb & (half - 1);
+                    v2f a0 = v[qa], b0 = v[qa | half], a1 = v[qb], b1 = v[qb | half];
+                    vdit2_m<CONJ>(a0, b0, tw[ca_ < nc ? ca_ : ca_ - nc], ca_ >= nc, a1, b1, tw[cb_ < nc ? cb_ : cb_ - nc], cb_ >= nc);
+                    v[qa] = b0, v[qa | half] = a0, v[qb] = b1, v[qb | half] = a1;
+                }
+            } else
 #pragma unroll
             for (int q0 = 0; q0 < NREG; ++q0) {
                 if (q0 & half) continue;
@@ -282,6 +330,52 @@ __device__ __forceinline__ void pair_regs_pk4(v2f A, v2f Bp, v2f w, uint32_t x1,
     VB = Us + S * cj;                                          // (sx + uy, ux - sy)
 }
 
+// The Hermitian fold as a PRODUCT (round 6). Without a frequency kernel |X[j]| = |X[N - j]| = m, so the folded bin is
+//   Zs[j] = m (e^{i th_j} + e^{-i th_{N-j}}) / 2 = m cos((th_j + th_{N-j}) / 2) e^{i (th_j - th_{N-j}) / 2}
+// (src/fft.rs:63-69 draws both phases; nothing about the draws changes): three transcendentals per folded bin instead
+// of four - v_cos of the half sum, v_cos / v_sin of the half difference - and the packed add of the two phasors becomes
+// a multiply. The half angles come straight from the draws (phase_g2_x): fa = 0.5 + (r1 + r2) / 2 is rounded to the
+// 2^-24 grid of [0.5, 1) (<= 2^-25 of a revolution = 1.9e-7 rad off), the half difference is exact.
+// v_cos(fa) = -cos(half sum): the result is HALF of pair_regs_pk4's (same sign), so callers scale by -1/(2N).
+template <int LOG2N, bool DC = false, bool BAND = false>
+__device__ __forceinline__ void pair_regs_pk5(v2f A, v2f Bp, v2f w, uint32_t x1, PhaseKey key, v2f &VA,
+                                              v2f &VB, bool dc = false, v2f gq = v2f{1.0f, 1.0f}) {
+    constexpr uint32_t N = 1u << LOG2N, M = N / 2;
+    const uint32_t cM = M * key.mul + 2u * key.k0;
+    const v2f cj = {1.0f, -1.0f}, jc = {-1.0f, 1.0f};
+    const v2f Bc = Bp * cj;                                    // conj(Bp) (fused into E, D by the compiler)
+    const v2f E = A + Bc, D = A - Bc;                          // 2E, 2D
+    const v2f T = cmul_fma(D, w, __builtin_shufflevector(D, D, 0, 0) * w);  // T = w D
+    const v2f U = __builtin_shufflevector(E, E, 0, 0) + __builtin_shufflevector(T, T, 1, 1) * cj;
+    const v2f V = __builtin_shufflevector(E, E, 1, 1) + __builtin_shufflevector(T, T, 0, 0) * jc;
+    const v2f q2 = __builtin_elementwise_fma(V, V, U * U);     // (|X1|^2, |X2c|^2)
+    v2f mm = v2f{__builtin_amdgcn_sqrtf(q2.x), __builtin_amdgcn_sqrtf(q2.y)};
+    if constexpr (BAND) mm = mm * gq;
+    float gl1, gu4, gl3, gu2;
+    phase_g2_x(x1, gl1, gu4);        // bins ja and M + ja
+    phase_g2_x(cM - x1, gl3, gu2);   // bins M - ja and N - ja
+    const v2f GU = {gu2, gu4}, GL = {gl1, gl3};
+    // pair 1 = bins (ja, N - ja): half sum / half difference of (th1, th2); pair 2 = bins (M + ja, M - ja): of (th4, th3)
+    v2f FA = __builtin_elementwise_fma(GU, v2f{0.5f, 0.5f}, GL);
+    v2f FB = __builtin_elementwise_fma(GU, v2f{-0.5f, 0.5f}, GL * cj);
+    if (DC) {  // bin 0 with itself: th2 := th1, th3 := th4 (half sums th1, th4; half differences 0)
+        FA = vsel(dc, v2f{gl1 + gl1, gu4}, FA);
+        FB = vsel(dc, v2f{0.0f, 0.0f}, FB);
+    }
+    const v2f ca = {__builtin_amdgcn_cosf(FA.x), __builtin_amdgcn_cosf(FA.y)};
+    const v2f E1 = {__builtin_amdgcn_cosf(FB.x), __builtin_amdgcn_sinf(FB.x)};
+    const v2f E2 = {__builtin_amdgcn_cosf(FB.y), __builtin_amdgcn_sinf(FB.y)};
+    const v2f km = ca * mm;
+    const v2f k1 = __builtin_shufflevector(km, km, 0, 0), k2 = __builtin_shufflevector(km, km, 1, 1);
+    const v2f Pz = E1 * k1;
+    const v2f S = __builtin_elementwise_fma(E2, k2, Pz);
+    const v2f R = __builtin_elementwise_fma(E2, -k2, Pz);
+    const v2f Uc = cmulc_fma(R, w, R * __builtin_shufflevector(w, w, 0, 0));  // conj(w) R
+    const v2f Us = __builtin_shufflevector(Uc, Uc, 1, 0);      // (uy, ux)
+    VA = S + Us * jc;                                          // (sx - uy, sy + ux)
+    VB = Us + S * cj;                                          // (sx + uy, ux - sy)
+}
+
 // ---- default-window fast path: windows::hanning (src/windows.rs:4-9) and the crossfade envelope
 // (src/crossfade.rs:4-10) are both 0.5 - c cos(2 pi i / (len - 1)). Thread t touches samples
 // i = 512 q + 2 t + e, so cos(alpha_q + beta_te) = cos alpha_q cos beta_te - sin alpha_q sin beta_te:
@@ -327,7 +421,11 @@ __device__ constexpr HannK HANN_W14 = make_hann_k(0.5, 16384, 32);
 __device__ constexpr HannK HANN_E14 = make_hann_k(HANN_ENV_AMP, 8192, 16);
 // synthesis window times -1/(4N) = -2^-16 (hop4: the scale of the magnitudes, src/fft.rs:72's / N and the sign
 // of the negated phasors, moved out of the per-bin stage; a power of two, so nothing rounds differently)
-constexpr double HANN_KAPPA = -0.25 / 16384.0;
+// (round 6: pair_regs_pk5 returns half of pair_regs_pk4's values, so with it the scale is -1/(2N) = -2^-15)
+#ifndef RC_FOLDPROD
+#define RC_FOLDPROD 1  // the Hermitian fold as a product (pair_regs_pk5); 0: as a sum of two phasors (pair_regs_pk4), for A/B
+#endif
+constexpr double HANN_KAPPA = (RC_FOLDPROD ? -0.5 : -0.25) / 16384.0;
 __device__ constexpr HannK HANN_W14K = make_hann_k(0.5 * HANN_KAPPA, 16384, 32);
 
 }  // namespace

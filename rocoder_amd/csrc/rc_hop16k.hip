@@ -426,7 +426,11 @@ __device__ __forceinline__ void wave_fence() {
 
 // Workgroup barrier of the hop loop. __syncthreads() also waits for vmcnt(0), i.e. for the previous hop's
 // output stores to be acknowledged; the exchanges only need this wave's LDS operations to have completed.
+#if RC_FOLDPROD
+#define HOP4_PAIR pair_regs_pk5
+#else
 #define HOP4_PAIR pair_regs_pk4
+#endif
 #define HOP4_BAR()                                                                    \
     do {                                                                              \
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                \
@@ -975,7 +979,7 @@ __global__ __launch_bounds__(256, 3) void hop4_kernel(const HopParams p) {
         const v2f half2k = {(float)(0.5 * HANN_KAPPA), (float)(0.5 * HANN_KAPPA)};
         if constexpr (TABW) {
             GF wt2 = per_hop(p.window) + lane2;
-            const v2f kap = half2k + half2k;  // -1/(4N)
+            const v2f kap = half2k + half2k;  // -1/(4N) (-1/(2N) with the product fold)
 #pragma unroll
             for (int q0 = 0; q0 < P; q0 += 4) {
                 float a0[4], a1[4];

@@ -175,7 +175,7 @@ class Engine:
         self.window_len = int(self._cfg.window_len)
 
     def close(self):
-        for o in getattr(self, "_views", {}).values():
+        for o in list((getattr(self, "_views", None) or {}).values()):
             o.current = False
         if getattr(self, "_h", None):
             self._L.rc_engine_destroy(self._h)
@@ -224,7 +224,13 @@ class Engine:
         if rc == RC_WOULD_BLOCK:
             return None
         owner = _ViewOwner(self, channel, C.addressof(p.contents), n.value * 4)
-        self._views = getattr(self, "_views", {})
+        # weak: the owner refers to the engine (an array keeps its engine alive), the engine must not refer back -
+        # a cycle through an object with __del__ would leave the engine, its HBM and its pinned blocks to a cyclic GC
+        # pass instead of the refcount
+        if getattr(self, "_views", None) is None:
+            import weakref
+
+            self._views = weakref.WeakValueDictionary()
         prev = self._views.get(channel)
         if prev is not None:
             prev.current = False

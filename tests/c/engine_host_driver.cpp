@@ -158,6 +158,57 @@ static void seam(uint32_t N, float f, int p, uint32_t ch, size_t L, uint32_t bat
     rc_engine_destroy(e);
 }
 
+// A closed job consumed in other orders than the processor's round-robin: one channel wholly before the next (the group
+// batches of stream_enqueue_group give way to per-channel batches once the channels part), channels of different
+// lengths (never a group), and a consumer that stops half way (blocks in flight at destroy).
+static void seam_orders(uint32_t N, float f, uint32_t ch, size_t L, uint32_t batch, int order) {
+    rc_config c = config(N, f, 1, ch);
+    c.max_batch_hops = batch;
+    rc_engine *e = nullptr;
+    CHECK(rc_engine_create(&c, &e) == RC_OK);
+    rc_params P;
+    CHECK(rc_engine_get_params(e, &P) == RC_OK);
+    auto x = input(ch, L);
+    std::vector<size_t> len(ch, L);
+    if (order == 1)
+        for (uint32_t i = 0; i < ch; ++i) len[i] = L - (size_t)i * (L / 4);  // unequal channels
+    for (uint32_t i = 0; i < ch; ++i) {
+        CHECK(rc_engine_push_input(e, i, x[i].data(), len[i]) == RC_OK);
+        CHECK(rc_engine_close_input(e, i) == RC_OK);
+    }
+    std::vector<size_t> total(ch, 0);
+    size_t n = 0;
+    const float *pv = nullptr;
+    if (order == 2) {  // round-robin, abandoned half way
+        const size_t half = rc_offline_output_len(&c, L) / 2;
+        while (total[0] < half)
+            for (uint32_t i = 0; i < ch; ++i) {
+                CHECK(rc_engine_next_window_view(e, i, &pv, &n) == RC_OK);
+                total[i] += n;
+            }
+        rc_engine_destroy(e);
+        return;
+    }
+    // a few windows round-robin first (the job starts as a group), then channel after channel
+    for (int w = 0; w < 3; ++w)
+        for (uint32_t i = 0; i < ch; ++i)
+            if (rc_engine_is_done(e, i) != 1) {
+                CHECK(rc_engine_next_window_view(e, i, &pv, &n) == RC_OK);
+                volatile float sink = pv[0] + pv[n - 1];
+                (void)sink;
+                total[i] += n;
+            }
+    for (uint32_t i = 0; i < ch; ++i)
+        while (rc_engine_is_done(e, i) != 1) {
+            CHECK(rc_engine_next_window_view(e, i, &pv, &n) == RC_OK);
+            volatile float sink = pv[0] + pv[n - 1];
+            (void)sink;
+            total[i] += n;
+        }
+    for (uint32_t i = 0; i < ch; ++i) CHECK(total[i] == rc_offline_output_len(&c, len[i]));
+    rc_engine_destroy(e);
+}
+
 static void multi(const std::vector<int32_t> &devs, uint32_t N, float f, int p, uint32_t ch, size_t L) {
     rc_config c = config(N, f, p, ch);
     rc_multi *m = nullptr;
@@ -225,6 +276,12 @@ int main() {
         seam(4096, 2.0f, 3, 1, 90000, 12, view);
         seam(2048, 2.0f, -2, 2, 50000, 4, view);
         seam(256, 0.3f, 1, 1, 20000, 0, view);
+        seam(16384, 8.0f, 1, 2, 2500000, 0, view);  // the default batch size: the ramp of the group batches (1/16, 1/4, 1)
+        seam(1024, 8.0f, 1, 8, 400000, 0, view);    // eight channels in one group
+    }
+    for (int order = 0; order < 3; ++order) {
+        seam_orders(4096, 4.0f, 2, 300000, 16, order);
+        seam_orders(16384, 8.0f, 3, 600000, 0, order);
     }
     // several devices in one process: the persistent workers, host and device form, in place and staged
     multi({0, 0, 0}, 16384, 8.0f, 1, 2, 300000);

@@ -21,29 +21,37 @@ import rocoder_amd  # noqa: E402
 from oracle import oracle_np as onp  # noqa: E402  (input synthesis only)
 from rocoder_amd.distributed import engine_compute, stretch_sharded  # noqa: E402
 
-torch.cuda.set_device(0)
-dev = torch.device("cuda", 0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+# WORLD_SIZE / RANK / LOCAL_RANK from the environment (the test starts one rank per GPU of the box: one on this pool)
+world = int(os.environ.get("WORLD_SIZE", "1"))
+rank = int(os.environ.get("RANK", "0"))
+local = int(os.environ.get("LOCAL_RANK", str(rank)))
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 res = {"backend": dist.get_backend(), "world": dist.get_world_size()}
-t = torch.tensor([3.5], dtype=torch.float64, device=dev)
+t = torch.tensor([3.5 + rank], dtype=torch.float64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 dist.barrier()
 res["all_reduce"] = float(t.item())
 x = torch.from_numpy(np.stack([onp.synth_input(c, 400000) for c in range(2)])).to(dev)
-with rocoder_amd.Engine(window_len=16384, factor=8.0, channels=2, seed=3) as e:
-    full = e.stretch_tensor(x).clone()
+with rocoder_amd.Engine(window_len=16384, factor=8.0, channels=2, seed=3, device=local) as e:
+    full = e.stretch_tensor(x).clone()  # every rank computes the whole job once: the reference the concat is held to
     wout = e.params.window_out_len
     nwin = full.shape[1] // wout
     comp = engine_compute(e, x)
     for name, kw in (("broadcast_all", dict(dst=None)), ("root_only", dict(dst=0)),
                      ("grouped_send_recv_to_self", dict(dst=0, stage_all=True))):
+        has_result = kw["dst"] is None or rank == kw["dst"]  # root-only forms: the other ranks get no tensor
         got = stretch_sharded(comp, 2, nwin, wout, **kw)
         torch.cuda.synchronize()
-        res[name] = bool(torch.equal(got, full))
-        buf = torch.full_like(full, float("nan"))
+        res[name] = bool(torch.equal(got, full)) if has_result else True
+        buf = torch.full_like(full, float("nan")) if has_result else None
         got2 = stretch_sharded(comp, 2, nwin, wout, full=buf, **kw)
         torch.cuda.synchronize()
-        res[name + "_into_caller_buffer"] = bool(got2 is buf and torch.equal(buf, full))
+        res[name + "_into_caller_buffer"] = bool(got2 is buf and torch.equal(buf, full)) if has_result else True
+        ok = torch.tensor([1.0 if (res[name] and res[name + "_into_caller_buffer"]) else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # rank 0's line speaks for every rank
+        res[name] = res[name] and bool(ok.item() == 1.0)
     e.synchronize()
 dist.barrier()
 dist.destroy_process_group()

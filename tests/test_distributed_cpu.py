@@ -107,3 +107,29 @@ def test_sharded_gather_gloo(world, dst):
         pr.join(timeout=60)
         assert pr.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def test_multi_device_test_lists_widen_with_the_device_count():
+    """tests/test_gpu_multi.py builds its device lists and the RCCL world from rc_device_count()
+    (tests/multi_devices.py). With the count faked: on a four-GPU box every multi-device test also runs on lists of
+    DISTINCT devices (neighbouring shards on different GPUs: real peer copies) and the RCCL test starts four ranks; on
+    this pool's one-GPU boxes the lists and the test count are what they were."""
+    from multi_devices import device_lists, rccl_world
+
+    assert device_lists(2, 1) == [[0, 0]] and device_lists(8, 1) == [[0] * 8]
+    assert device_lists(2, 4) == [[0, 0], [0, 1]]
+    assert device_lists(3, 4) == [[0, 0, 0], [0, 1, 2]]
+    assert device_lists(8, 4) == [[0] * 8, [0, 1, 2, 3, 0, 1, 2, 3]]
+    assert device_lists(8, 8) == [[0] * 8, list(range(8))]
+    for n_have in (2, 4, 8):
+        for n_dev in (2, 3, 4, 8):
+            spread = device_lists(n_dev, n_have)[-1]
+            assert len(spread) == n_dev and max(spread) == min(n_dev, n_have) - 1
+            assert all(a != b for a, b in zip(spread, spread[1:]))  # neighbours never share a device
+    assert [rccl_world(n) for n in (1, 2, 4, 8, 16)] == [1, 2, 4, 8, 8]
+    # the shard plan the lists are indexed by: shard i of an n-way cut runs on ids[i] - with the spread list on 4 GPUs
+    # a stereo job cut 4 ways puts its four half-channels on four devices
+    from rocoder_amd.distributed import shard_plan
+
+    ids = device_lists(4, 4)[-1]
+    assert sorted({ids[s.rank] for s in shard_plan(2, 1000, 4)}) == [0, 1, 2, 3]

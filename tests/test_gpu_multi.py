@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
+from multi_devices import device_lists, rccl_world
 from oracle import oracle_np as onp
 
 pytestmark = pytest.mark.gpu
@@ -19,6 +20,12 @@ def _ra():
 
     assert _lib.lib().rc_device_count() > 0
     return rocoder_amd
+
+
+def _n_have():
+    from rocoder_amd import _lib
+
+    return int(_lib.lib().rc_device_count())
 
 
 @pytest.mark.parametrize("n_dev", [2, 3, 8])
@@ -34,20 +41,23 @@ def test_multi_device_equals_one_engine_bit_for_bit(n_dev, N, f, p, ch, L):
     x = np.stack([onp.synth_input(c, L) for c in range(ch)])
     with ra.Engine(window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=99) as e:
         one = e.stretch_host(x)
-    with ra.MultiEngine([0] * n_dev, window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=99) as m:
-        got_h = m.stretch_host(x)
-        xt = torch.from_numpy(x).cuda()
-        # every listed "device" is the root's own GPU here: by default its shares compute in place...
-        got_ip = m.stretch_tensor(xt, root=n_dev - 1).cpu().numpy()
-        # ... and with forced staging they take a remote device's path: span copy in, compute, shard copy out
-        m.set_staging(True)
-        got_d = m.stretch_tensor(xt, root=n_dev - 1).cpu().numpy()
-        got_d2 = m.stretch_tensor(xt, root=0).cpu().numpy()  # (buffers of the first call are reused)
-    assert got_h.shape == one.shape
-    assert np.array_equal(got_h, one)
-    assert np.array_equal(got_ip, one)
-    assert np.array_equal(got_d, one)
-    assert np.array_equal(got_d2, one)
+    # [0] * n_dev always; on a box with several GPUs also the list spread over DISTINCT devices (real peer copies)
+    for ids in device_lists(n_dev, _n_have()):
+        with ra.MultiEngine(ids, window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=99) as m:
+            got_h = m.stretch_host(x)
+            # the tensors live on the root of the list: both ends of it are tried
+            x_last, x_first = (torch.from_numpy(x).to(f"cuda:{ids[r]}") for r in (n_dev - 1, 0))
+            # a share on the root's own device computes in place...
+            got_ip = m.stretch_tensor(x_last, root=n_dev - 1).cpu().numpy()
+            # ... and with forced staging it takes a remote device's path: span copy in, compute, shard copy out
+            m.set_staging(True)
+            got_d = m.stretch_tensor(x_last, root=n_dev - 1).cpu().numpy()
+            got_d2 = m.stretch_tensor(x_first, root=0).cpu().numpy()  # (buffers of the first call are reused)
+        assert got_h.shape == one.shape, ids
+        assert np.array_equal(got_h, one), ids
+        assert np.array_equal(got_ip, one), ids
+        assert np.array_equal(got_d, one), ids
+        assert np.array_equal(got_d2, one), ids
 
 
 @pytest.mark.parametrize("L,n_dev", [(0, 2), (700, 3), (1024, 8), (1500, 4)])
@@ -60,12 +70,13 @@ def test_multi_device_edge_lengths(L, n_dev):
     x = np.stack([onp.synth_input(c, L) for c in range(2)]) if L else np.zeros((2, 0), np.float32)
     with ra.Engine(window_len=1024, factor=2.0, channels=2, seed=5) as e:
         one = e.stretch_host(x)
-    with ra.MultiEngine([0] * n_dev, window_len=1024, factor=2.0, channels=2, seed=5) as m:
-        assert np.array_equal(m.stretch_host(x), one)
-        xt = torch.from_numpy(x).cuda() if L else torch.zeros((2, 0), device="cuda")
-        assert np.array_equal(m.stretch_tensor(xt, root=n_dev - 1).cpu().numpy(), one)
-        m.set_staging(True)
-        assert np.array_equal(m.stretch_tensor(xt, root=0).cpu().numpy(), one)
+    for ids in device_lists(n_dev, _n_have()):
+        with ra.MultiEngine(ids, window_len=1024, factor=2.0, channels=2, seed=5) as m:
+            assert np.array_equal(m.stretch_host(x), one), ids
+            x_last, x_first = ((torch.from_numpy(x) if L else torch.zeros((2, 0))).to(f"cuda:{ids[r]}") for r in (n_dev - 1, 0))
+            assert np.array_equal(m.stretch_tensor(x_last, root=n_dev - 1).cpu().numpy(), one), ids
+            m.set_staging(True)
+            assert np.array_equal(m.stretch_tensor(x_first, root=0).cpu().numpy(), one), ids
 
 
 def test_multi_device_refuses_a_host_kernel_and_a_bad_root():
@@ -135,24 +146,37 @@ def test_multi_device_from_plain_c(tmp_path):
 
 @pytest.mark.gpu
 def test_rccl_one_rank_walks_the_sharded_concat():
-    """the RCCL branch of rocoder_amd.distributed (communicator creation, broadcast into shard
-    views, the grouped send / recv launch) executes on hardware, bit-exact against the single-engine tensor. One rank:
-    RCCL refuses two ranks on one device, and the box has one."""
+    """the RCCL branch of rocoder_amd.distributed (communicator creation, broadcast
+    into shard views, the grouped send / recv launch) executes on hardware, bit-exact against the single-engine tensor.
+    One rank PER GPU of the box (at most 8), each started as a fresh child process on its own device (RCCL refuses two
+    ranks on one device): with one GPU it is the one-rank walk of round 5, on a node it is a real concat over xGMI."""
     import json
     import socket
     import sys
 
+    world = rccl_world(_n_have())
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
-        env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank.py")], env=env,
-                       capture_output=True, text=True, timeout=420)
-    assert r.returncode == 0, r.stderr[-3000:]
-    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert res["backend"] == "nccl" and res["world"] == 1 and res["all_reduce"] == 3.5
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               WORLD_SIZE=str(world))
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_one_rank.py")],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=420))
+    finally:
+        for p in procs:  # exactly the children started above
+            if p.poll() is None:
+                p.kill()
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, (r, se[-3000:])
+    res = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
+    assert res["backend"] == "nccl" and res["world"] == world and res["all_reduce"] == 3.5 + (world - 1)
     for k in ("broadcast_all", "root_only", "grouped_send_recv_to_self"):
         assert res[k] is True and res[k + "_into_caller_buffer"] is True, res
 

@@ -628,6 +628,78 @@ def test_next_window_view_and_look_ahead_equal_the_copying_seam(N, f, p, batch):
         assert_parity(a[c], ref[c], f"view seam ch{c}", reg=REG_TOL if f >= 0.5 else 5e-6)
 
 
+@pytest.mark.parametrize("N,f,ch,L", [(16384, 8.0, 2, 2_600_000), (1024, 8.0, 8, 300_000), (65536, 32.0, 3, 400_000)])
+@pytest.mark.parametrize("order", ["round_robin", "channel_after_channel", "unequal_lengths"])
+def test_closed_job_group_batches_equal_the_offline_job_bit_for_bit(N, f, ch, L, order):
+    """Round 6: on a closed job the seam computes EVERY channel's next windows in one launch and
+    lets the batch grow (1/16, 1/4, 1 of up to 64 MiB per channel). What comes out of next_window / next_window_view,
+    in any order of asking, is the offline job (rc_engine_stretch_device on the same input: one launch, the parity
+    tests' subject) bit for bit: the processor's round-robin (group batches throughout), one channel drained before
+    the next (the group gives way to per-channel batches), channels of different lengths (never a group)."""
+    import torch
+
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, L) for c in range(ch)])
+    lens = [L - (c * (L // 5) if order == "unequal_lengths" else 0) for c in range(ch)]
+    with ra.Engine(window_len=N, factor=f, channels=ch, seed=11) as e:
+        refs = []
+        for c in range(ch):  # (per length: the offline job of a shorter channel is a job of its own)
+            xt = torch.from_numpy(np.ascontiguousarray(x[:, :lens[c]])).cuda()
+            refs.append(e.stretch_tensor(xt)[c].cpu().numpy())
+    with ra.Engine(window_len=N, factor=f, channels=ch, seed=11) as e:
+        for c in range(ch):
+            e.push_input(c, x[c, :lens[c]])
+            e.close_input(c)
+        wins = [[] for _ in range(ch)]
+        if order == "channel_after_channel":
+            for _ in range(3):  # starts as a group ...
+                for c in range(ch):
+                    wins[c].append(np.array(e.next_window_view(c)))
+            for c in range(ch):  # ... then the channels part
+                while not e.is_done(c):
+                    wins[c].append(e.next_window(c).copy())
+        else:
+            live = list(range(ch))
+            while live:
+                for c in list(live):
+                    if e.is_done(c):
+                        live.remove(c)
+                        continue
+                    w = e.next_window_view(c) if (len(wins[c]) & 1) else e.next_window(c)
+                    wins[c].append(np.array(w))
+        for c in range(ch):
+            got = np.concatenate(wins[c])
+            assert got.shape == refs[c].shape, (c, got.shape, refs[c].shape)
+            assert np.array_equal(got, refs[c]), f"channel {c} ({order})"
+
+
+def test_views_do_not_keep_a_dropped_engine_alive():
+    """Engine._views held its view owners strongly and every owner held the engine - a cycle through an
+    object with __del__, so a dropped engine (its HBM, its pinned blocks) waited for a cyclic GC pass. Now the engine
+    refers to the owners weakly: with the collector off, dropping the last array and the engine frees it at once,
+    while a live view still keeps its engine."""
+    import gc
+    import weakref
+
+    ra = _engine_mod()
+    gc.collect()
+    gc.disable()
+    try:
+        e = ra.Engine(window_len=1024, factor=4.0, channels=1, seed=1)
+        e.push_input(0, onp.synth_input(0, 30000))
+        e.close_input(0)
+        a = e.next_window_view(0)
+        b = e.next_window_view(0)
+        assert e.view_is_current(b) and not e.view_is_current(a)
+        r = weakref.ref(e)
+        del e
+        assert r() is not None and r().view_is_current(b)  # the view keeps the engine
+        del a, b
+        assert r() is None, "the engine survived its last reference: a cycle again"
+    finally:
+        gc.enable()
+
+
 def test_streaming_speedup_factor_below_half():
     """sample_step_len > window_len through the streaming seam (push / next_window), ragged chunks."""
     ra = _engine_mod()
@@ -1111,7 +1183,10 @@ def test_hop4_agrees_with_previous_kernel_generation(monkeypatch, p):
     side path); everything else is hop3_kernel's operation for operation (the first hop4, which kept the
     side path, was bit-identical). hop3 stays in the test-hook library (make hooks) behind ROCODER_DIAG=2 for this check and for
     A/B timing: the two must agree far inside the tolerance (hop4 also fuses the analysis window into the
-    first butterfly stage and folds the amplitude into the envelope, so single roundings differ)."""
+    first butterfly stage and folds the amplitude into the envelope, so single roundings differ). Round 6: hop4
+    takes the Hermitian fold as a product (three transcendentals per folded bin, pair_regs_pk5): the half-sum angle
+    is rounded to 2^-25 of a revolution, which moves the result by 3e-7 of the RMS against hop3's sum of two phasors
+    (both sit at 1.5e-7 ... 4e-7 of the RMS from the oracle); the bound went from 2e-7 to 5e-7."""
     import torch
 
     ra = _engine_mod()
@@ -1129,7 +1204,7 @@ def test_hop4_agrees_with_previous_kernel_generation(monkeypatch, p):
     assert torch.isfinite(new).all() and float(new.abs().max()) > 0.01
     d = (new.double() - old.double())
     rel = float(d.pow(2).mean().sqrt() / old.double().pow(2).mean().sqrt())
-    assert rel <= 2e-7, rel
+    assert rel <= 5e-7, rel
 
 
 def test_baseline_c1_full_size_every_sample():
