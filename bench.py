@@ -1017,6 +1017,10 @@ def seam_numbers():
         sb.seam_bench_live.argtypes = [C.c_char_p, C.c_uint32, C.c_float, C.c_uint32, C.c_float, C.c_uint32,
                                        C.POINTER(C.c_double)]
         lib = _lib.LIB_PATH.encode()
+        # what `numactl --cpunodebind` does for a host program: the hand-out thread (this one) on the CPUs next to the GPU,
+        # for the seam legs only (the engine prefers that node's memory for its pinned blocks by itself)
+        affinity = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+        node = sb.seam_bench_pin_near_gpu()
         seam = {}
         for name, view in (("copy", 0), ("view", 1)):
             best, push = 0.0, 0.0
@@ -1029,7 +1033,8 @@ def seam_numbers():
                     best, push = sps.value, pms.value
             seam[f"{name}_Msamples_s"] = round(best / 1e6, 1)
             seam[f"{name}_push_ms"] = round(push, 1)
-        seam["job"] = f"closed stereo job, L={L_IN}/ch, window {WINDOW}, factor {FACTOR:g}; round-robin over the channels; best of 2"
+        seam["job"] = (f"closed stereo job, L={L_IN}/ch, window {WINDOW}, factor {FACTOR:g}; round-robin over the channels; best of 2; "
+                       f"calling thread on the CPUs of the GPU's NUMA node ({node})" + ("" if node >= 0 else ": not found, unpinned"))
         out["streaming_seam"] = seam
         live = {}
         for buf in (1.0, 0.1):
@@ -1043,6 +1048,8 @@ def seam_numbers():
         live["what"] = ("open stereo channels, window 16384, factor 8: push of one window's input advance (2048 samples) per "
                         "channel -> rc_engine_next_window returns; 1000 rounds after 8 untimed ones")
         out["live_latency_us"] = live
+        if affinity is not None:
+            os.sched_setaffinity(0, affinity)
     except Exception as ex:  # noqa: BLE001
         out.setdefault("streaming_seam", {})["error"] = f"{type(ex).__name__}: {ex}"[:300]
     return out

@@ -79,6 +79,19 @@ hipError_t hipHostFree(void *p) {
     free(p);
     return hipSuccess;
 }
+hipError_t hipDeviceGetPCIBusId(char *, int, int) { return hipErrorInvalidDevice; }  // (no sysfs entry to look up here)
+// the engine page-locks anonymous memory it mapped itself (pinned_alloc): the block joins the page-locked set
+hipError_t hipHostRegister(void *p, size_t n, unsigned) {
+    if (!p || !n) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_host.count(p)) return hipErrorHostMemoryAlreadyRegistered;
+    g_host[p] = n;
+    return hipSuccess;
+}
+hipError_t hipHostUnregister(void *p) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_host.erase(p) ? hipSuccess : hipErrorHostMemoryNotRegistered;
+}
 hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) {
     *d = h;
     return hipSuccess;

@@ -2,6 +2,8 @@
 // out of a pinned block the DMA engine wrote. hipcc -O2 -o tools/bin/hostbench tools/hostbench.cpp
 #include <hip/hip_runtime.h>
 
+#include <sys/mman.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -73,6 +75,40 @@ int main() {
             printf("%s: D2H 64 MiB %.2f ms (%.1f GB/s), hand-out %.2f ms = %.2f Gsamples/s [%g]\n",
                    mode == 0 ? "memcpy" : mode == 1 ? "memcpy+prefetch" : "view", (t1 - t0) * 1e3, bytes / (t1 - t0) / 1e9,
                    (t2 - t1) * 1e3, bytes / 4 / (t2 - t1) / 1e9, acc);
+        }
+    // the same block as anonymous memory with transparent huge pages, populated, then registered
+    for (int huge = 0; huge < 2; ++huge)
+        for (int rep = 0; rep < 2; ++rep) {
+            const size_t len = bytes + ((size_t)2 << 20);
+            double t0 = now();
+            char *raw = (char *)mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (raw == MAP_FAILED) return 2;
+            char *al = (char *)(((uintptr_t)raw + ((size_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1));
+            if (huge) madvise(al, bytes, MADV_HUGEPAGE);
+            double t1 = now();
+            if (madvise(al, bytes, 23 /* MADV_POPULATE_WRITE */) != 0) memset(al, 0, bytes);
+            double t2 = now();
+            CK(hipHostRegister(al, bytes, hipHostRegisterDefault));
+            double t3 = now();
+            float *hh = (float *)al;
+            CK(hipMemcpy(hh, d, bytes, hipMemcpyDeviceToHost));
+            double t4 = now();
+            CK(hipMemcpy(hh, d, bytes, hipMemcpyDeviceToHost));
+            double t5 = now();
+            double acc = 0;
+            for (size_t o = 0; o < bytes / 4; o += win) {
+                memcpy(out, hh + o, win * 4);
+                acc += out[0];
+            }
+            double t6 = now();
+            CK(hipHostUnregister(al));
+            double t7 = now();
+            munmap(raw, len);
+            double t8 = now();
+            printf("mmap%s 64 MiB: map %.2f ms, populate %.2f ms, register %.2f ms, first D2H %.2f ms, second D2H %.2f ms (%.1f GB/s), "
+                   "memcpy hand-out %.2f ms = %.2f Gsamples/s, unregister %.2f ms, munmap %.2f ms [%g]\n", huge ? "+THP" : "", (t1 - t0) * 1e3,
+                   (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t5 - t4) * 1e3, bytes / (t5 - t4) / 1e9, (t6 - t5) * 1e3,
+                   bytes / 4 / (t6 - t5) / 1e9, (t7 - t6) * 1e3, (t8 - t7) * 1e3, acc);
         }
     // fresh destination per window (what a Vec<f32> per next_window costs): 64 KiB malloc + copy + free
     {

@@ -5,7 +5,10 @@
  * engine library is resolved at run time from the path the caller gives (the product library or an A/B variant), so this
  * file links against nothing.
  *   standalone: gcc -O2 -DSEAM_BENCH_MAIN -I include -o /tmp/seam_bench tools/seam_bench.c -ldl -lm && /tmp/seam_bench rocoder_amd/librocoder_hip.so */
+#define _GNU_SOURCE
+#include <ctype.h>
 #include <dlfcn.h>
+#include <sched.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -49,6 +52,46 @@ static int load(const char *path, api *a) {
     SYM(last_error, "rc_last_error");
 #undef SYM
     return 0;
+}
+
+/* What `numactl --cpunodebind=<the GPU's node>` does for a host program: the calling thread runs on the CPUs next to
+ * device 0 (sysfs local_cpulist of its PCI address, which the HIP runtime the engine library brought in reports). Returns
+ * the NUMA node, or -1 when anything is missing (the thread then stays where the scheduler put it). */
+int seam_bench_pin_near_gpu(void) {
+    int (*bus_id)(char *, int, int) = NULL;
+    *(void **)(&bus_id) = dlsym(RTLD_DEFAULT, "hipDeviceGetPCIBusId");
+    char bdf[64] = {0}, path[160], buf[4096];
+    if (!bus_id || bus_id(bdf, (int)sizeof bdf - 1, 0) != 0) return -1;
+    for (char *q = bdf; *q; ++q) *q = (char)tolower((unsigned char)*q);
+    int node = -1;
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE *f = fopen(path, "r");
+    if (f) {
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+    f = fopen(path, "r");
+    if (!f) return -1;
+    if (!fgets(buf, sizeof buf, f)) buf[0] = 0;
+    fclose(f);
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int any = 0;
+    for (char *q = buf; *q;) {  /* "0-63,128-191" */
+        if (!isdigit((unsigned char)*q)) {
+            ++q;
+            continue;
+        }
+        long a = strtol(q, &q, 10), b = a;
+        if (*q == '-') b = strtol(q + 1, &q, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) {
+            CPU_SET((int)c, &set);
+            any = 1;
+        }
+    }
+    if (!any || sched_setaffinity(0, sizeof set, &set) != 0) return -1;
+    return node;
 }
 
 static rc_config config(uint32_t window, float factor, uint32_t channels, float buffer_secs) {
@@ -105,6 +148,8 @@ int seam_bench_closed(const char *libpath, uint32_t window, float factor, uint32
     const double t1 = now();
     uint64_t total = 0;
     double acc = 0;
+    const int trace = getenv("SEAM_BENCH_TRACE") != NULL;  /* dev: every hand-out that took longer than 50 us */
+    uint64_t call_i = 0;
     for (;;) {  /* src/stretcher_processor.rs:63-70: stop at the first channel that is done */
         int stop = 0;
         for (uint32_t ch = 0; ch < channels; ++ch) {
@@ -113,6 +158,7 @@ int seam_bench_closed(const char *libpath, uint32_t window, float factor, uint32
                 break;
             }
             size_t n = 0;
+            const double tc0 = trace ? now() : 0;
             if (view) {
                 const float *w = NULL;
                 if ((rc = a.view(e, ch, &w, &n)) != RC_OK) goto done;
@@ -121,6 +167,12 @@ int seam_bench_closed(const char *libpath, uint32_t window, float factor, uint32
                 if ((rc = a.next(e, ch, out, P.window_out_len, &n)) != RC_OK) goto done;
                 acc += out[0];
             }
+            if (trace) {
+                const double tc1 = now();
+                if (tc1 - tc0 > 50e-6)
+                    fprintf(stderr, "call %llu ch %u at %.2f ms: %.3f ms\n", (unsigned long long)call_i, ch, (tc0 - t1) * 1e3, (tc1 - tc0) * 1e3);
+            }
+            call_i++;
             total += n;
         }
         if (stop) break;
@@ -211,6 +263,11 @@ done:
 int main(int argc, char **argv) {
     const char *lib = argc > 1 ? argv[1] : "rocoder_amd/librocoder_hip.so";
     const uint32_t channels = argc > 2 ? (uint32_t)atoi(argv[2]) : 2;
+    {
+        api a;
+        if (load(lib, &a)) return 1;
+        if (!(argc > 3 && !strcmp(argv[3], "nopin"))) printf("thread on the CPUs of the GPU's NUMA node %d\n", seam_bench_pin_near_gpu());
+    }
     for (int rep = 0; rep < 2; ++rep)
         for (int view = 0; view < 2; ++view) {
             double sps = 0, push = 0;
