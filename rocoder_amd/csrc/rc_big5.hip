@@ -1,5 +1,7 @@
 #include "rc_bigdit.hpp"
 
+#include <type_traits>
+
 namespace rc {
 namespace {
 
@@ -79,24 +81,64 @@ constexpr B5Tab make_b5tab() {
 }
 __device__ constexpr B5Tab B5 = make_b5tab();
 
+#ifndef BIG5_ST_AUX
+#define BIG5_ST_AUX 2  // cache policy of the output stores: 2 = nt; 16 = sc1, 17 = sc0 sc1 (write-through: A/B, round 6)
+#endif
 #define BIG5_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // wave-local exchanges: the LDS runs one wave's instructions in order; the compiler must not move a load over a store
 #define BIG5_FENCE() asm volatile("" ::: "memory")
 
-template <bool PITCH1, bool HANN>
+// SEAM (round 6, pitch 1): hop4_kernel's run hand-over at 64 Ki. Runs are SHORT (16 hops) and handed out per XCD in the
+// order workgroups start (HW_REG_XCC_ID tickets), so the 32 workgroups resident on an XCD walk 32 ADJACENT runs: their
+// 256 KB windows lie within 2.3 MB of input, which stays in the XCD's 4 MB L2 - every input byte comes over the fabric
+// about once instead of once per hop (round 5: 10.7 GB of window reads per C5 launch, L2 hit rate 30 %). A run does not
+// recompute the hop before it: run g > 0 stashes the windowed head of its first hop (write-through stores + flag) and run
+// g - 1 adds its last tail to it at its end (sc1 loads), as in rc_hop16k.hip.
+template <bool PITCH1, bool HANN, bool SEAM = false>
 __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
+    static_assert(!SEAM || PITCH1, "the seam hand-over stores whole heads: pitch 1");
     constexpr int R = BIG5_R, b = 6, m = 15, LOG2N = 16, M = 1 << m, H = M, T = BIG5_T;
     constexpr int RES = 2048, NS = 4, PH = R / 2, RG = BIG5_REGION;
     constexpr int T_A = BIG5_XBUF, SCR = T_A + BIG5_TA;
     constexpr int TL = BIG5_TAIL_LDS, TLB = SCR + 1, PHR = R / 2 - TL;  // tail pairs [PHR, R/2) live at lds[TLB + ...]
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
-    const uint32_t run = blockIdx.x % p.runs_per_channel;
-    const uint32_t ch = blockIdx.x / p.runs_per_channel;
+    uint32_t gr = blockIdx.x;
+    if constexpr (SEAM) {
+        // the ticket: XCD x walks the x-th eighth of the runs; an XCD that runs out takes from the next one's counter
+        // (rc_hop16k.hip). Read back through readfirstlane: run, channel and hop counter then live in SGPRs.
+        unsigned *slot = reinterpret_cast<unsigned *>(lds);
+        if (tid == 0) {
+            const uint32_t total = p.runs_per_channel * p.n_channels;
+            unsigned got = 0xFFFFFFFFu;
+            const uint32_t G = (total + 7u) / 8u;
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            for (uint32_t i = 0; i < 8u; ++i) {
+                const uint32_t xx = (xcc + i) & 7u, lo = xx * G;
+                if (lo >= total) continue;
+                const uint32_t hi = lo + G < total ? lo + G : total;
+                const uint32_t t = atomicAdd(p.run_counter + xx, 1u);
+                if (t < hi - lo) {
+                    got = lo + t;
+                    break;
+                }
+            }
+            *slot = got;
+        }
+        __syncthreads();
+        gr = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<volatile unsigned *>(slot));
+        __syncthreads();
+        if (gr == 0xFFFFFFFFu) return;  // (more workgroups than runs: cannot happen with the engine's grid)
+    }
+    const uint32_t run = gr % p.runs_per_channel;
+    const uint32_t ch = gr / p.runs_per_channel;
     const int64_t k_begin = p.hop_first + (int64_t)run * p.run_len;
     int64_t k_end = k_begin + p.run_len;
     if (k_end > p.hop_first + p.hop_count) k_end = p.hop_first + p.hop_count;
     if (k_begin >= k_end) return;
+    const bool stash_first = SEAM && run > 0;
+    const bool has_next = SEAM && run + 1 < p.runs_per_channel;
     GF xc = (GF)p.x + (size_t)ch * p.in_stride;
     GF xt = (GF)p.xtail + (size_t)ch * p.tail_stride;
     GFW outc = (GFW)p.out + (size_t)ch * p.out_stride;
@@ -144,7 +186,7 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
     };
     // (a 32-bit trip count: the scalar unit has no ordered 64-bit compare, so `k < k_end` on int64 ran on the VALU with
     // k_end parked in a VGPR pair - this kernel's one scratch reload per hop)
-    const int64_t k_first = k_begin > 0 ? k_begin - 1 : k_begin;
+    const int64_t k_first = (k_begin > 0 && !stash_first) ? k_begin - 1 : k_begin;
     const int n_it = (int)(k_end - k_first);
     for (int it = 0; it < n_it; ++it) {
         const int64_t k = k_first + it;
@@ -520,18 +562,24 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
             }
         }
         stp.mark(9);
-        // ---- epilogue: inverse stage 14, synthesis window, overlap-add, store (big4_kernel<64>'s)
-        {
+        // ---- epilogue: inverse stage 14, synthesis window, overlap-add, store (big4_kernel<64>'s).
+        // STASH (SEAM, the first hop of a run g > 0): the windowed head goes to the seam stash as it is (write-through
+        // stores: the run before adds its last tail to it, maybe from another XCD), the tail is kept as always.
+        auto epilogue = [&](auto stash_tag) {
+            constexpr bool STASH = decltype(stash_tag)::value;
             GF win = per_hop(p.window);
             GF esrc = per_hop(p.env);
             v2f cbW = {0.f, 0.f}, sbW = cbW, cbE = cbW, sbE = cbW;
             if constexpr (HANN) {
                 GV2 hr = (GV2)per_hop(p.hann_rot) + 2 * tt;
-                const float2 a0 = ldg2(hr), a1 = ldg2(hr + 1), e0r = ldg2(hr + 2 * T), e1r = ldg2(hr + 2 * T + 1);
+                const float2 a0 = ldg2(hr), a1 = ldg2(hr + 1);
                 cbW = v2f{a0.x, a1.x};
                 sbW = v2f{a0.y, a1.y};
-                cbE = v2f{e0r.x, e1r.x};
-                sbE = v2f{e0r.y, e1r.y};
+                if constexpr (!STASH) {
+                    const float2 e0r = ldg2(hr + 2 * T), e1r = ldg2(hr + 2 * T + 1);
+                    cbE = v2f{e0r.x, e1r.x};
+                    sbE = v2f{e0r.y, e1r.y};
+                }
             }
             const HannK64 &HW = HANN_W16;
             const HannK64 &HE = HANN_E16;
@@ -546,7 +594,7 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
                 hfE = hf * ampk;
             }
             const int64_t g0 = k * (int64_t)H;
-            GFW dst = outc + (g0 / (int64_t)pitch - p.out_origin);
+            GFW dst = STASH ? (GFW)p.seam_head + (size_t)gr * H : outc + (g0 / (int64_t)pitch - p.out_origin);
             const uint32_t kr = (uint32_t)(g0 % pitch);
             const unsigned long long da = (unsigned long long)dst;  // (uniform: descriptor in SGPRs)
             const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
@@ -564,19 +612,26 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
                         wr1[q] = (win + 2 * T * (q0 + q))[lane2 + 1];
                         wt0[q] = (win + 2 * T * (q0 + q + PH))[lane2];
                         wt1[q] = (win + 2 * T * (q0 + q + PH))[lane2 + 1];
-                        e0[q] = (esrc + 2 * T * (q0 + q))[lane2];
-                        e1[q] = (esrc + 2 * T * (q0 + q))[lane2 + 1];
+                        if constexpr (!STASH) {
+                            e0[q] = (esrc + 2 * T * (q0 + q))[lane2];
+                            e1[q] = (esrc + 2 * T * (q0 + q))[lane2 + 1];
+                        }
                     } else {
                         const v2f wh = __builtin_elementwise_fma(v2f{HW.s[q0 + q], HW.s[q0 + q]}, sbW,
                                        __builtin_elementwise_fma(v2f{HW.c[q0 + q], HW.c[q0 + q]}, cbW, hf));
                         const v2f wt = __builtin_elementwise_fma(v2f{HW.s[q0 + q + PH], HW.s[q0 + q + PH]}, sbW,
                                        __builtin_elementwise_fma(v2f{HW.c[q0 + q + PH], HW.c[q0 + q + PH]}, cbW, hf));
-                        const v2f ev = __builtin_elementwise_fma(v2f{HE.s[q0 + q], HE.s[q0 + q]}, sbE,
-                                       __builtin_elementwise_fma(v2f{HE.c[q0 + q], HE.c[q0 + q]}, cbE, hfE));
-                        wr0[q] = wh.x, wr1[q] = wh.y, wt0[q] = wt.x, wt1[q] = wt.y, e0[q] = ev.x, e1[q] = ev.y;
+                        wr0[q] = wh.x, wr1[q] = wh.y, wt0[q] = wt.x, wt1[q] = wt.y;
+                        if constexpr (!STASH) {
+                            const v2f ev = __builtin_elementwise_fma(v2f{HE.s[q0 + q], HE.s[q0 + q]}, sbE,
+                                           __builtin_elementwise_fma(v2f{HE.c[q0 + q], HE.c[q0 + q]}, cbE, hfE));
+                            e0[q] = ev.x, e1[q] = ev.y;
+                        }
                     }
-                    if (q0 + q < PHR) tq[q] = tail[q0 + q];
-                    else tq[q] = to_v(lds[TLB + 512 * (q0 + q - PHR) + tt]);
+                    if constexpr (!STASH) {
+                        if (q0 + q < PHR) tq[q] = tail[q0 + q];
+                        else tq[q] = to_v(lds[TLB + 512 * (q0 + q - PHR) + tt]);
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < EB; ++q) {
@@ -590,15 +645,24 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
                         if (c < 16) vdit_m<true>(a, bb, tw, yh, yt);
                         else vdit_rot_m<true>(a, bb, tw, yh, yt);
                     }
-                    const v2f head = yh * v2f{wr0[q], wr1[q]};
+                    v2f head = yh * v2f{wr0[q], wr1[q]};
+                    // (the windowed head is ROUNDED before the tail is added, as the reference's Vec<f32> is
+                    // (src/fft.rs:72-73, src/stretcher.rs:97-100) and as a head that went through the seam stash is: with
+                    // -ffp-contract=fast the compiler made it fma(yh, w, tail), one rounding, and a run seam differed
+                    // from the same hop inside a run by an ulp)
+                    asm volatile("" : "+v"(head));
                     const v2f nt = yt * v2f{wt0[q], wt1[q]};
-                    if (k >= k_begin) {
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    if constexpr (STASH) {  // (16 = sc1: write-through, as the atomic stores of rc_hop16k.hip's stash)
+                        __builtin_amdgcn_raw_buffer_store_b64(v2u{__float_as_uint(head.x), __float_as_uint(head.y)}, rd,
+                                                              (int)(4u * lane2), 4 * 2 * T * (q0 + q), 16);
+                    } else if (k >= k_begin) {
                         // stretcher.rs:97-100; with the computed envelope the amplitude is already inside it
                         const v2f o = HANN ? (head + tq[q]) * v2f{e0[q], e1[q]} : (head + tq[q]) * v2f{e0[q], e1[q]} * ampk;
                         if constexpr (PITCH1) {
-                            typedef unsigned v2u __attribute__((ext_vector_type(2)));  // (buffer store, aux 2 = nt, as the loads)
+                            // (buffer store, aux 2 = nt, as the loads)
                             __builtin_amdgcn_raw_buffer_store_b64(v2u{__float_as_uint(o.x), __float_as_uint(o.y)}, rd,
-                                                                  (int)(4u * lane2), 4 * 2 * T * (q0 + q), 2);
+                                                                  (int)(4u * lane2), 4 * 2 * T * (q0 + q), BIG5_ST_AUX);
                         } else {
                             const uint32_t a0 = kr + 2u * (uint32_t)(tid + T * (q0 + q)), a1 = a0 + 1;
                             const uint32_t d0 = a0 / pitch, d1 = a1 / pitch;
@@ -611,6 +675,17 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        if (SEAM && stash_first && it == 0) {
+            epilogue(std::true_type{});
+            // every storing wave drains its own write-through stores before the barrier; only then may lane 0 publish
+            // (MI355X_MICROARCH.md, valid hand-off forms)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0 && !(p.diag_flags & RC_DIAG_SKIP_SEAM_PUBLISH))
+                __hip_atomic_store(p.seam_flag + gr, p.seam_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            epilogue(std::false_type{});
         }
         stp.mark(10);
     }
@@ -620,6 +695,72 @@ __global__ __launch_bounds__(BIG5_T, 2) void big5_kernel(const HopParams p) {
         for (int i = 0; i < 32; ++i) dbg[i] = stp.acc[i];
     }
 #endif
+    if constexpr (SEAM) {
+        if (!has_next) return;
+        // the run's seam: wait for the head the next run stashed at its start (it started long ago: it is the next ticket
+        // of this XCD, or the first run of the next eighth), add this run's last tail, envelope, store hop k_end's head
+        unsigned *okw = reinterpret_cast<unsigned *>(lds);  // (the exchange buffer: no wave reads it after its last E4 loads)
+        if (tid == 0) {
+            unsigned ok = 0;
+            for (unsigned spin = 0; spin < p.seam_spin_limit; ++spin) {
+                if (__hip_atomic_load(p.seam_flag + gr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == p.seam_epoch) {
+                    ok = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(32);
+            }
+            if (!ok && p.err_word)
+                __hip_atomic_store(p.err_word, RC_ERR_SEAM_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            *okw = ok;
+        }
+        __syncthreads();
+        if (*reinterpret_cast<volatile unsigned *>(okw) == 0) return;
+        int tt = tid;
+        opaque(tt);
+        const unsigned long long sa = (unsigned long long)(p.seam_head + (size_t)(gr + 1) * H);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sa >> 32)) << 32) |
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)sa)), 0, 0x40000000, 0x00020000);
+        const unsigned long long da = (unsigned long long)(outc + (k_end * (int64_t)H - p.out_origin));
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(da >> 32)) << 32) |
+                     (unsigned)__builtin_amdgcn_readfirstlane((int)da)), 0, 0x40000000, 0x00020000);
+        const float ak = p.amp * (-0.25f / (float)(1 << LOG2N));
+        const v2f ampk = {ak, ak};
+        v2f cbE = {0.f, 0.f}, sbE = cbE, hfE = v2f{0.5f, 0.5f} * ampk;
+        if constexpr (HANN) {
+            GV2 hr = (GV2)p.hann_rot + 2 * tt;
+            const float2 e0r = ldg2(hr + 2 * T), e1r = ldg2(hr + 2 * T + 1);
+            cbE = v2f{e0r.x, e1r.x} * ampk;
+            sbE = v2f{e0r.y, e1r.y} * ampk;
+        }
+        const HannK64 &HE = HANN_E16;
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        constexpr int SB = 8;
+#pragma unroll
+        for (int q0 = 0; q0 < PH; q0 += SB) {
+            v2u hd[SB];
+#pragma unroll
+            for (int q = 0; q < SB; ++q)  // (sc1 loads: every load of the handed-over bytes bypasses this CU's L1)
+                hd[q] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(4u * lane2), 4 * 2 * T * (q0 + q), 16);
+#pragma unroll
+            for (int q = 0; q < SB; ++q) {
+                const v2f head = {__uint_as_float(hd[q].x), __uint_as_float(hd[q].y)};
+                const v2f tq = (q0 + q < PHR) ? tail[q0 + q] : to_v(lds[TLB + 512 * (q0 + q - PHR) + tt]);
+                v2f o;
+                if constexpr (HANN) {
+                    const v2f ev = __builtin_elementwise_fma(v2f{HE.s[q0 + q], HE.s[q0 + q]}, sbE,
+                                   __builtin_elementwise_fma(v2f{HE.c[q0 + q], HE.c[q0 + q]}, cbE, hfE));
+                    o = (head + tq) * ev;
+                } else {
+                    GF esrc = (GF)p.env;
+                    o = (head + tq) * v2f{(esrc + 2 * T * (q0 + q))[lane2], (esrc + 2 * T * (q0 + q))[lane2 + 1]} * ampk;
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(v2u{__float_as_uint(o.x), __float_as_uint(o.y)}, rd, (int)(4u * lane2),
+                                                      4 * 2 * T * (q0 + q), BIG5_ST_AUX);
+            }
+        }
+    }
 }
 
 
@@ -962,7 +1103,10 @@ hipError_t launch_big5(const HopParams &p, hipStream_t s) {
     const dim3 grid(p.runs_per_channel * p.n_channels), block(BIG5_T);
     const size_t lds = sizeof(float2) * (size_t)big5_lds_float2();
     const bool hann = p.hann_rot != nullptr;
-    if (p.pitch == 1 && hann) hipLaunchKernelGGL((big5_kernel<true, true>), grid, block, lds, s, p);
+    // (the engine sets the stash up for pitch 1 and the default window only: with a caller's window the seam
+    // instantiation spills 45 registers)
+    if (p.seam_head != nullptr && p.pitch == 1 && hann) hipLaunchKernelGGL((big5_kernel<true, true, true>), grid, block, lds, s, p);
+    else if (p.pitch == 1 && hann) hipLaunchKernelGGL((big5_kernel<true, true>), grid, block, lds, s, p);
     else if (p.pitch == 1) hipLaunchKernelGGL((big5_kernel<true, false>), grid, block, lds, s, p);
     else if (hann) hipLaunchKernelGGL((big5_kernel<false, true>), grid, block, lds, s, p);
     else hipLaunchKernelGGL((big5_kernel<false, false>), grid, block, lds, s, p);

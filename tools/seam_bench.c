@@ -60,6 +60,13 @@ static int load(const char *path, api *a) {
 int seam_bench_pin_near_gpu(void) {
     int (*bus_id)(char *, int, int) = NULL;
     *(void **)(&bus_id) = dlsym(RTLD_DEFAULT, "hipDeviceGetPCIBusId");
+    if (!bus_id) {  /* (a host that loaded the engine library RTLD_LOCAL, e.g. through ctypes: ask for the runtime by name) */
+        const char *names[] = {"libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6", NULL};
+        for (int i = 0; names[i] && !bus_id; ++i) {
+            void *h = dlopen(names[i], RTLD_LAZY | RTLD_NOLOAD);
+            if (h) *(void **)(&bus_id) = dlsym(h, "hipDeviceGetPCIBusId");
+        }
+    }
     char bdf[64] = {0}, path[160], buf[4096];
     if (!bus_id || bus_id(bdf, (int)sizeof bdf - 1, 0) != 0) return -1;
     for (char *q = bdf; *q; ++q) *q = (char)tolower((unsigned char)*q);
