@@ -1248,19 +1248,20 @@ def test_big4_agrees_with_three_kernel_pipeline_at_c5_size(monkeypatch):
         assert float(d.abs().max()) <= 1e-4, c
 
 
-def test_seam_wait_expiry_fails_loudly(monkeypatch):
-    """The run-seam hand-over of the N = 16384 kernel has a bounded wait. With the diagnostic flag that
-    makes producers skip the publish (ROCODER_DIAG=1), consumers must give up, leave a device error
-    word and the engine must return RC_EHIP - never silently consume a stale stash."""
+@pytest.mark.parametrize("N,f,L", [(16384, 8.0, 1_200_000), (65536, 32.0, 1_600_000)])
+def test_seam_wait_expiry_fails_loudly(monkeypatch, N, f, L):
+    """The run-seam hand-over of the N = 16384 kernel - and, since round 6, of the N = 65536 kernel - has a bounded
+    wait. With the diagnostic flag that makes producers skip the publish (ROCODER_DIAG=1), consumers must give up,
+    leave a device error word and the engine must return RC_EHIP - never silently consume a stale stash."""
     import torch
 
     ra = _engine_mod()
     from rocoder_amd import _lib
 
-    x = np.stack([onp.synth_input(c, 1_200_000) for c in range(2)])
+    x = np.stack([onp.synth_input(c, L) for c in range(2)])
     xt = torch.from_numpy(x).cuda()
     monkeypatch.setenv("ROCODER_DIAG", "1")
-    with _lib.hooks_library(), ra.Engine(window_len=16384, factor=8.0, channels=2, seed=3) as e:
+    with _lib.hooks_library(), ra.Engine(window_len=N, factor=f, channels=2, seed=3) as e:
         with pytest.raises(_lib.RocoderError) as ei:
             e.stretch_tensor(xt)  # (asynchronous on a caller stream: the error then comes from the next call)
             torch.cuda.synchronize()
@@ -1268,7 +1269,7 @@ def test_seam_wait_expiry_fails_loudly(monkeypatch):
         assert ei.value.code == _lib.RC_EHIP and "seam" in str(ei.value)
         e.synchronize()  # reported once
     # the product library ignores the variable altogether
-    with ra.Engine(window_len=16384, factor=8.0, channels=2, seed=3) as e:
+    with ra.Engine(window_len=N, factor=f, channels=2, seed=3) as e:
         out = e.stretch_tensor(xt)
         torch.cuda.synchronize()
         e.synchronize()
