@@ -61,7 +61,7 @@ typedef struct rc_config {
     float buffer_secs;       /* -b/--buffer (Duration, default 1 s) */
     uint64_t seed;           /* phase-source seed (replaces thread_rng, src/fft.rs:64) */
     int32_t device;          /* HIP device ordinal */
-    uint32_t max_batch_hops; /* streaming look-ahead cap per launch; 0 = default */
+    uint32_t max_batch_hops; /* streaming look-ahead cap per launch and channel; 0 = default (8 MiB of windows) */
     const float *window;     /* host, window_len floats; NULL = windows::hanning (main.rs:131) */
     rc_freq_kernel kernel;   /* --freq-kernel; NULL = none */
     void *kernel_user;
@@ -145,7 +145,8 @@ int rc_engine_next_window(rc_engine *e, uint32_t channel, float *out, size_t out
  * pinned host block, valid until the next rc_engine_next_window / _view call on the SAME channel. The reference moves
  * a freshly allocated Vec<f32> into the bounded queue (src/stretcher.rs:112-120, src/stretcher_processor.rs:69); a
  * host that writes the window straight to its sink (src/main.rs:197-203: the WAV writer) needs no Vec at all. On a
- * closed channel (whole input known) the batch after the one being handed out is computed and copied meanwhile. */
+ * closed channel (whole input known) the batches after the one being handed out - every closed channel's together, up to
+ * two in flight - are computed and copied meanwhile. */
 int rc_engine_next_window_view(rc_engine *e, uint32_t channel, const float **window, size_t *n_out);
 /* Stretcher::is_done (src/stretcher.rs:78-80): 1 / 0, or <0 on error. */
 int rc_engine_is_done(const rc_engine *e, uint32_t channel);

@@ -31,7 +31,8 @@ def _n_have():
 @pytest.mark.parametrize("n_dev", [2, 3, 8])
 @pytest.mark.parametrize("N,f,p,ch,L", [(16384, 8.0, 1, 2, 700_000), (16384, 8.0, 3, 2, 300_000),
                                         (16384, 8.0, 1, 3, 400_000), (1024, 2.0, 2, 1, 50_000),
-                                        (65536, 32.0, 1, 8, 150_000), (4096, 0.3, 1, 2, 90_000)])
+                                        (65536, 32.0, 1, 8, 150_000), (4096, 0.3, 1, 2, 90_000),
+                                        (65536, 32.0, 1, 2, 1_500_000)])  # (long enough for big5's run seams, cut differently per plan)
 def test_multi_device_equals_one_engine_bit_for_bit(n_dev, N, f, p, ch, L):
     """Host form and device form, every shard plan: identical bits to the same job on one engine (hops are a pure
     function of (seed, channel, hop, bin); each shard recomputes the hop before its range)."""

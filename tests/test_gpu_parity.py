@@ -1176,6 +1176,35 @@ def test_baseline_full_size_every_sample(cfg):
         del got, ref
 
 
+@pytest.mark.parametrize("C,L", [(1, 2_500_000), (3, 1_300_000), (5, 900_000), (3, 4_000_000)])
+def test_window_65536_run_seams_every_sample(C, L):
+    """Round 6: big5_kernel's run seams (runs of ~16 hops per XCD ticket, stash hand-over) in other shapes than C5's
+    8 x 5 106 hops: one, three and five channels, one round of the 256 workgroups and three, run counts that are no
+    multiple of 8 (uneven eighths: an XCD that runs out takes tickets from the next one's counter). EVERY output sample
+    against the oracle-checked fast CPU restatement, with the per-block gate that catches a single bad seam."""
+    import torch
+
+    ra = _engine_mod()
+    N, f, seed = 65536, 32.0, 0x5EED
+    x = np.stack([onp.synth_input(c, L) for c in range(C)])
+    with ra.Engine(window_len=N, factor=f, channels=C, seed=seed) as e:
+        got_t = e.stretch_tensor(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        e.synchronize()
+    nt = _host_threads()
+    block = N // 2
+    for c in range(C):
+        ref = oc.cpu_baseline_stretch(x[c:c + 1], N, f, 1.0, 1, seed=seed, threads=nt, ch_first=c)[0]
+        got = got_t[c].cpu().numpy()
+        assert got.shape == ref.shape and np.isfinite(got).all()
+        d = got.astype(np.float64) - ref
+        r = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+        err = float(np.sqrt(np.mean(d * d)))
+        blk = np.sqrt((d[:d.size // block * block].reshape(-1, block) ** 2).mean(axis=1))
+        assert err <= TOL and err <= FAST_REG * r, f"ch{c}: {err / r:.2e} of rms_ref"
+        assert float(blk.max()) / r <= FAST_BLOCK, f"ch{c}: worst block {float(blk.max()) / r:.2e} at hop {int(blk.argmax())}"
+
+
 @pytest.mark.parametrize("p", [1, 3])
 def test_hop4_agrees_with_previous_kernel_generation(monkeypatch, p):
     """hop4_kernel changes which thread holds which elements between passes (wave-local exchanges) and how
