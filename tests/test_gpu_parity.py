@@ -628,25 +628,27 @@ def test_next_window_view_and_look_ahead_equal_the_copying_seam(N, f, p, batch):
         assert_parity(a[c], ref[c], f"view seam ch{c}", reg=REG_TOL if f >= 0.5 else 5e-6)
 
 
-@pytest.mark.parametrize("N,f,ch,L", [(16384, 8.0, 2, 2_600_000), (1024, 8.0, 8, 300_000), (65536, 32.0, 3, 400_000)])
+@pytest.mark.parametrize("N,f,ch,L,p", [(16384, 8.0, 2, 2_600_000, 1), (1024, 8.0, 8, 300_000, 1), (65536, 32.0, 3, 400_000, 1),
+                                        (4096, 2.0, 2, 300_000, 3), (2048, 2.0, 2, 150_000, -2), (3000, 4.0, 2, 120_000, 1)])
 @pytest.mark.parametrize("order", ["round_robin", "channel_after_channel", "unequal_lengths"])
-def test_closed_job_group_batches_equal_the_offline_job_bit_for_bit(N, f, ch, L, order):
+def test_closed_job_group_batches_equal_the_offline_job_bit_for_bit(N, f, ch, L, p, order):
     """Round 6: on a closed job the seam computes EVERY channel's next windows in one launch and
     lets the batch grow (1/16, 1/4, 1 of up to 64 MiB per channel). What comes out of next_window / next_window_view,
     in any order of asking, is the offline job (rc_engine_stretch_device on the same input: one launch, the parity
     tests' subject) bit for bit: the processor's round-robin (group batches throughout), one channel drained before
-    the next (the group gives way to per-channel batches), channels of different lengths (never a group)."""
+    the next (the group gives way to per-channel batches), channels of different lengths (never a group); pitch 3
+    and -2 (windows of another length than N) and a window length that is no power of two."""
     import torch
 
     ra = _engine_mod()
     x = np.stack([onp.synth_input(c, L) for c in range(ch)])
     lens = [L - (c * (L // 5) if order == "unequal_lengths" else 0) for c in range(ch)]
-    with ra.Engine(window_len=N, factor=f, channels=ch, seed=11) as e:
+    with ra.Engine(window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=11) as e:
         refs = []
         for c in range(ch):  # (per length: the offline job of a shorter channel is a job of its own)
             xt = torch.from_numpy(np.ascontiguousarray(x[:, :lens[c]])).cuda()
             refs.append(e.stretch_tensor(xt)[c].cpu().numpy())
-    with ra.Engine(window_len=N, factor=f, channels=ch, seed=11) as e:
+    with ra.Engine(window_len=N, factor=f, pitch_multiple=p, channels=ch, seed=11) as e:
         for c in range(ch):
             e.push_input(c, x[c, :lens[c]])
             e.close_input(c)
