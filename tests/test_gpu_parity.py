@@ -675,6 +675,36 @@ def test_closed_job_group_batches_equal_the_offline_job_bit_for_bit(N, f, ch, L,
             assert np.array_equal(got, refs[c]), f"channel {c} ({order})"
 
 
+def test_engine_serves_offline_calls_and_the_seam_in_turn():
+    """One handle, used the three ways a host may: the offline call, then the streaming seam over the same input (its
+    batches come down on the engine's copy stream, out of buffers of their own), then - with windows still in flight -
+    the offline call again. All three are the same bits."""
+    import torch
+
+    ra = _engine_mod()
+    x = np.stack([onp.synth_input(c, 1_500_000) for c in range(2)])
+    xt = torch.from_numpy(x).cuda()
+    with ra.Engine(window_len=16384, factor=8.0, channels=2, seed=8) as e:
+        a = e.stretch_tensor(xt).clone()
+        torch.cuda.synchronize()
+        for c in range(2):
+            e.push_input(c, x[c])
+            e.close_input(c)
+        wins = [[], []]
+        n_half = a.shape[1] // e.params.window_out_len // 2
+        for _ in range(n_half):
+            for c in range(2):
+                wins[c].append(np.array(e.next_window_view(c)))
+        b = e.stretch_tensor(xt).clone()  # (two batches of the seam are still in flight)
+        torch.cuda.synchronize()
+        while not e.is_done(0):
+            for c in range(2):
+                wins[c].append(e.next_window(c).copy())
+        assert torch.equal(a, b)
+        for c in range(2):
+            assert np.array_equal(np.concatenate(wins[c]), a[c].cpu().numpy()), c
+
+
 def test_views_do_not_keep_a_dropped_engine_alive():
     """Engine._views held its view owners strongly and every owner held the engine - a cycle through an
     object with __del__, so a dropped engine (its HBM, its pinned blocks) waited for a cyclic GC pass. Now the engine
@@ -1205,6 +1235,44 @@ def test_window_65536_run_seams_every_sample(C, L):
         blk = np.sqrt((d[:d.size // block * block].reshape(-1, block) ** 2).mean(axis=1))
         assert err <= TOL and err <= FAST_REG * r, f"ch{c}: {err / r:.2e} of rms_ref"
         assert float(blk.max()) / r <= FAST_BLOCK, f"ch{c}: worst block {float(blk.max()) / r:.2e} at hop {int(blk.argmax())}"
+
+
+def test_run_seams_are_bit_reproducible_under_uneven_load():
+    """The two kernels with run seams (hop4_kernel at window 16384, big5_kernel at 65536: per-XCD run tickets, stash +
+    flag hand-over between runs) on two streams AT THE SAME TIME, repeatedly: the chip's CUs are shared unevenly
+    (a big5 workgroup takes a whole CU's LDS, hop4's take a third), tickets are handed out in another order every time,
+    seams are waited for - and every launch must still produce the bits of the same job run alone (MI355X_MICROARCH.md:
+    test every hand-off under uneven load, checking every word)."""
+    import torch
+
+    ra = _engine_mod()
+    x5 = torch.from_numpy(np.stack([onp.synth_input(c, 1_400_000) for c in range(8)])).cuda()
+    x2 = torch.from_numpy(np.stack([onp.synth_input(c, 3_000_000) for c in range(2)])).cuda()
+    with ra.Engine(window_len=65536, factor=32.0, channels=8, seed=21) as e5, \
+            ra.Engine(window_len=16384, factor=8.0, channels=2, seed=22) as e2:
+        ref5 = e5.stretch_tensor(x5).clone()
+        torch.cuda.synchronize()
+        ref2 = e2.stretch_tensor(x2).clone()
+        torch.cuda.synchronize()
+        s5, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        o5, o2 = torch.empty_like(ref5), torch.empty_like(ref2)
+        for rep in range(5):
+            o5.fill_(float("nan"))
+            o2.fill_(float("nan"))
+            torch.cuda.synchronize()
+            with torch.cuda.stream(s2):
+                for _ in range(2 + rep % 2):  # (a different overlap each time)
+                    e2.stretch_tensor(x2, out=o2)
+            with torch.cuda.stream(s5):
+                e5.stretch_tensor(x5, out=o5)
+            with torch.cuda.stream(s2):
+                e2.stretch_tensor(x2, out=o2)
+            s5.synchronize()
+            s2.synchronize()
+            e5.synchronize()
+            e2.synchronize()
+            assert torch.equal(o5, ref5), f"window 65536, repetition {rep}"
+            assert torch.equal(o2, ref2), f"window 16384, repetition {rep}"
 
 
 @pytest.mark.parametrize("p", [1, 3])
